@@ -1,0 +1,122 @@
+/*
+ * rdx.h — C-ABI of librdx, the MI355X (gfx950) dense-retrieval hot path that stands in for
+ * RAG-DPO's `embedding_provider.embed(...)` L2-normalise step and Chroma `collection.query(...)`.
+ *
+ * The reference (MatJoss/RAG-DPO) has no FFI of its own: its boundary is two duck-typed Python
+ * objects. Each entry point below names the reference call it replaces; the
+ * Python mirror of those objects (rag_dpo_amd/collection.py, embedding_provider.py) binds these
+ * symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 (RDX_OK) or an RDX_ERR_* code; rdx_last_error() gives the
+ *     thread-local message of the last failure on the calling thread.
+ *   - `space` says where EVERY pointer argument of that call lives: RDX_HOST or RDX_DEVICE
+ *     (device = the index's HIP device). Caller owns all buffers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the library's own stream for that index).
+ *     RDX_HOST calls are synchronous; RDX_DEVICE calls are enqueued on `stream` and return at once.
+ *   - rows are addressed by their insertion index ("row id", int64, 0-based); the Python layer
+ *     maps row ids to Chroma string ids / documents / metadatas.
+ *   - scores are cosine similarities in fp32: exact dot product of the two L2-normalised fp32
+ *     vectors accumulated in fp64 in a fixed order (oracle/rdx_oracle.c states the order), rounded
+ *     once to fp32. Chroma's `distance` is `1.0f - score` ("hnsw:space": "cosine",
+ *     reference src/processing/create_chromadb_index.py:100-106).
+ *   - result order per query: score descending, ties by ascending row id (= ascending distance,
+ *     the order `RAGRetriever._parse_chromadb_results` consumes, reference src/rag/retriever.py:472-494).
+ */
+#ifndef RDX_H
+#define RDX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDX_OK 0
+#define RDX_ERR_INVALID 1 /* bad argument: shape, k, NaN/Inf in input, unknown option */
+#define RDX_ERR_HIP 2     /* HIP runtime failure (message carries hipGetErrorString) */
+#define RDX_ERR_NOMEM 3   /* device or host allocation failed */
+#define RDX_ERR_STATE 4   /* call not valid in the index's current state */
+
+#define RDX_HOST 0
+#define RDX_DEVICE 1
+
+#define RDX_ABI_VERSION 1
+
+typedef struct rdx_index rdx_index; /* opaque: one corpus shard resident in one GPU's HBM */
+
+/* Library / device ---------------------------------------------------------------------------- */
+int rdx_version(void);
+const char* rdx_last_error(void);
+int rdx_device_count(int* n);
+
+/* Index lifecycle — replaces chromadb `create_collection(..., {"hnsw:space": "cosine"})` /
+ * `get_collection` (reference create_chromadb_index.py:100-106,112; app.py:58-59). */
+int rdx_index_create(int device, int dim, rdx_index** out);
+int rdx_index_destroy(rdx_index* h);
+int rdx_index_dim(const rdx_index* h, int* dim);
+/* `collection.count()` (reference src/rag/bm25_index.py:200, app.py:108). */
+int rdx_index_count(const rdx_index* h, int64_t* rows);
+int rdx_index_reserve(rdx_index* h, int64_t rows);
+
+/* `collection.add(embeddings=...)` (reference create_chromadb_index.py:374-379,
+ * ingest_enterprise.py:241-246): append n raw fp32 rows [n][dim]; each is L2-normalised on the
+ * device (K1) into the fp32 master copy and the tiled fp16 scan copy. Row ids continue from
+ * count(). Rows containing NaN/Inf are rejected (RDX_ERR_INVALID) and nothing is added. */
+int rdx_index_add(rdx_index* h, const float* rows, int64_t n, int space);
+/* Config 5 (BASELINE.json): corpus delivered as bf16 (raw 16-bit patterns); the master copy
+ * holds the bf16 values widened to fp32 and normalised like any other row. */
+int rdx_index_add_bf16(rdx_index* h, const uint16_t* rows, int64_t n, int space);
+/* `collection.update(ids=, embeddings=)` / upsert: overwrite existing rows in place. */
+int rdx_index_update(rdx_index* h, const int64_t* row_ids, const float* rows, int64_t n, int space);
+/* `collection.get(include=["embeddings"])`: the stored (normalised) fp32 rows. */
+int rdx_index_get(rdx_index* h, const int64_t* row_ids, int64_t n, float* out, int space);
+/* `collection.delete(ids=...)` (reference ingest_enterprise.py:272,304): keep exactly the rows
+ * listed in `keep` (strictly ascending, host pointer), renumbering them 0..n_keep-1. */
+int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep);
+
+/* Options (tests and benchmarks): "force_exact" 0/1, "force_fast" 0/1 (MFMA scan even for small
+ * problems), "sample_div" >=1, "cand_cap" 0 (auto) or >=64,
+ * "profile" 0/1 (record HIP events around every kernel of the next searches). */
+int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);
+
+/* `SentenceTransformer.encode(..., normalize_embeddings=True)`'s last step
+ * (reference src/utils/embedding_provider.py:139-145): out[i] = in[i] / max(||in[i]||_2, 1e-12). */
+int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space,
+                     void* stream);
+
+/* `collection.query(query_embeddings=, n_results=k, where=)` (reference
+ * src/rag/retriever.py:215-220,380-385; create_chromadb_index.py:405-408,435-439).
+ *   queries     [nq][dim] raw fp32 (normalised on the device like corpus rows)
+ *   allow_bits  NULL, or ceil(count/32) words: bit (r&31) of word r>>5 set = row r may be
+ *               returned (the `where` pre-filter and tombstones, evaluated by the host layer)
+ *   out_score   [nq][k] fp32 cosine, out_row [nq][k] int64 row ids, out_count [nq] number of valid
+ *               entries (= min(k, allowed rows)); unused tail entries are (-inf, -1). */
+int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k, const uint32_t* allow_bits,
+               float* out_score, int64_t* out_row, int32_t* out_count, int space, void* stream);
+
+/* Multi-GPU exchange step: merge n_parts per-shard partial results (after the RCCL all-gather,
+ * SURVEY.md §8e) into the global top-k with the same ordering rule. Layouts:
+ * part_score/part_row [n_parts][nq][k], part_count [n_parts][nq]; row ids must already be global. */
+int rdx_merge_topk(int device, const float* part_score, const int64_t* part_row,
+                   const int32_t* part_count, int n_parts, int64_t nq, int k, float* out_score,
+                   int64_t* out_row, int32_t* out_count, int space, void* stream);
+
+/* Diagnostics of the last rdx_search on this index (valid after the stream has synchronised). */
+typedef struct rdx_search_stats {
+    int64_t nq, k, rows;
+    int64_t sample_rows;      /* rows scanned by the threshold bootstrap pass */
+    int64_t emitted;          /* candidates emitted by the main scan (sum over queries) */
+    int64_t rescored;         /* candidates re-scored exactly (sum over queries) */
+    int64_t exact_queries;    /* queries answered by the exact full scan (fallback / small path) */
+    int32_t path;             /* 0 = MFMA scan + exact re-score, 1 = exact scan only */
+    int32_t profiled;         /* 1 if the ms_* fields below were measured */
+    float ms_normalize, ms_scan_sample, ms_tau, ms_scan_main, ms_refine, ms_exact, ms_total;
+    int64_t scan_main_launch_rows, scan_main_launch_queries; /* units of the dominant kernel */
+} rdx_search_stats;
+int rdx_search_last_stats(rdx_index* h, rdx_search_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDX_H */

@@ -1,0 +1,113 @@
+// k_refine.hpp — K4: exact re-score + final ordering of the scan's candidates, and C1's merge of per-shard
+// partial results after the RCCL all-gather.
+#pragma once
+#include "k_rows.hpp"
+
+namespace rdx {
+
+constexpr int REFINE_PMAX = 1024;   // most candidates re-scored exactly per query; more -> exact full scan
+
+struct RefineCounters {   // one per index, zeroed before every search
+    unsigned long long emitted;
+    unsigned long long rescored;
+    int n_exact;          // queries handed to the exact full scan
+    int pad;
+};
+
+// One block (256 threads) per query.
+//   cand[q][0..cnt) = (coarse score, row) of every allowed row whose coarse score >= tau[q].
+//   c_k = k-th largest coarse score. Every true top-k row has coarse >= c_k - 2E (|coarse-exact| <= E and k rows
+//   reach coarse c_k, hence exact c_k - E), so P = {coarse >= c_k - 2E} contains the exact top-k; P is re-scored
+//   exactly from the fp32 master copy (fp64 lane-order sum, oracle/rdx_oracle.c) and ranked (score desc, row asc).
+//   Overflow of the candidate list or of P cannot be answered here: the query is flagged for the exact scan.
+__global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cnt,
+                                                uint32_t cap, int k, float two_e, const float* __restrict__ qhat,
+                                                const float* __restrict__ master, int dim, int64_t row_base,
+                                                float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                                int32_t* __restrict__ out_count, int32_t* __restrict__ exact_list,
+                                                RefineCounters* __restrict__ ctr) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t bc[4];
+    __shared__ float s_s[REFINE_PMAX];
+    __shared__ int64_t s_r[REFINE_PMAX];
+    __shared__ int n_p;
+    const int q = blockIdx.x;
+    const uint32_t m = cnt[q];
+    float* o_s = out_score + (int64_t)q * k;
+    int64_t* o_r = out_row + (int64_t)q * k;
+    if (threadIdx.x == 0) atomicAdd(&ctr->emitted, (unsigned long long)m);
+    if (m > cap) {
+        if (threadIdx.x == 0) exact_list[atomicAdd(&ctr->n_exact, 1)] = q;
+        return;
+    }
+    if (m == 0 || k == 0) {
+        rank_and_write(s_s, s_r, 0, k, o_s, o_r, out_count + q);
+        return;
+    }
+    const uint2* c = cand + (int64_t)q * cap;
+    const int64_t kk = (uint32_t)k < m ? k : m;
+    int64_t n_gt;
+    const uint32_t kth = block_kth_largest([&](int64_t i) { return f2key(__uint_as_float(c[i].x)); }, m, kk, hist, bc, &n_gt);
+    const float t2 = key2f(kth) - two_e;
+    if (threadIdx.x == 0) n_p = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        const uint2 e = c[i];
+        if (__uint_as_float(e.x) >= t2) {
+            const int pos = atomicAdd(&n_p, 1);
+            if (pos < REFINE_PMAX) s_r[pos] = (int64_t)e.y;
+        }
+    }
+    __syncthreads();
+    const int p = n_p;
+    if (p > REFINE_PMAX) {
+        if (threadIdx.x == 0) exact_list[atomicAdd(&ctr->n_exact, 1)] = q;
+        return;
+    }
+    if (threadIdx.x == 0) atomicAdd(&ctr->rescored, (unsigned long long)p);
+    // exact re-score: one wave per candidate row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* q4 = reinterpret_cast<const float4*>(qhat + (int64_t)q * dim);
+    for (int i = wave; i < p; i += 4) {
+        const float4* row4 = reinterpret_cast<const float4*>(master + s_r[i] * (int64_t)dim);
+        const float s = exact_score(row4, q4, dim >> 2, lane);
+        if (lane == 0) s_s[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < p; i += blockDim.x) s_r[i] += row_base;
+    __syncthreads();
+    rank_and_write(s_s, s_r, p, k, o_s, o_r, out_count + q);
+}
+
+// C1. merge n_parts partial top-k lists per query. One block per query; n_parts*k <= MERGE_MAX.
+constexpr int MERGE_MAX = 4096;
+__global__ __launch_bounds__(256) void k_merge(const float* __restrict__ part_score, const int64_t* __restrict__ part_row,
+                                               const int32_t* __restrict__ part_count, int n_parts, int64_t nq, int k,
+                                               float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                               int32_t* __restrict__ out_count) {
+    __shared__ float s_s[MERGE_MAX];
+    __shared__ int64_t s_r[MERGE_MAX];
+    __shared__ int base[65];
+    const int64_t q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int p = 0; p < n_parts; ++p) {
+            base[p] = acc;
+            int c = part_count[(int64_t)p * nq + q];
+            acc += c < 0 ? 0 : (c > k ? k : c);
+        }
+        base[n_parts] = acc;
+    }
+    __syncthreads();
+    for (int p = 0; p < n_parts; ++p) {
+        const int c = base[p + 1] - base[p];
+        for (int i = threadIdx.x; i < c; i += blockDim.x) {
+            s_s[base[p] + i] = part_score[((int64_t)p * nq + q) * k + i];
+            s_r[base[p] + i] = part_row[((int64_t)p * nq + q) * k + i];
+        }
+    }
+    __syncthreads();
+    rank_and_write(s_s, s_r, base[n_parts], k, out_score + q * k, out_row + q * k, out_count + q);
+}
+
+}  // namespace rdx

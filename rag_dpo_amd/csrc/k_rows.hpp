@@ -1,0 +1,264 @@
+// k_rows.hpp — row-wise kernels: K1 L2-normalise (+ tiled fp16 scan copy), gather, exact scoring, dense select.
+// One 64-lane wavefront owns one row: 16 B/lane coalesced loads, fp64 lane-order sums (oracle/rdx_oracle.c).
+#pragma once
+#include "rdx_common.hpp"
+
+namespace rdx {
+
+// write the 4 consecutive elements k..k+3 of a normalised row into the tiled fp16 copy
+__device__ __forceinline__ void shadow_store4(_Float16* __restrict__ shadow, int64_t row, int k, int ksteps,
+                                              float scale, float4 y) {
+    half4 h;
+    h[0] = (_Float16)(y.x * scale);   // RNE; y * 2^s is exact
+    h[1] = (_Float16)(y.y * scale);
+    h[2] = (_Float16)(y.z * scale);
+    h[3] = (_Float16)(y.w * scale);
+    *reinterpret_cast<half4*>(shadow + shadow_off(row, k, ksteps)) = h;
+}
+
+// K1. out = in / max(|in|_2, 1e-12)  — SentenceTransformer.encode(normalize_embeddings=True),
+// reference src/utils/embedding_provider.py:139-145; also what `collection.add` needs for the cosine
+// space (reference src/processing/create_chromadb_index.py:100-106,374-379).
+// Destination row of input row i is dst_rows ? dst_rows[i] : row0 + i.
+__global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in, const uint16_t* __restrict__ in_bf16,
+                                                   int64_t n, int dim, const int64_t* __restrict__ dst_rows,
+                                                   int64_t row0, float* __restrict__ master,
+                                                   _Float16* __restrict__ shadow, int ksteps, float scale,
+                                                   int* __restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int n4 = dim >> 2;
+    auto load4 = [&](int g) -> float4 {
+        if (in_bf16) {
+            const ushort4 u = reinterpret_cast<const ushort4*>(in_bf16 + i * (int64_t)dim)[g];
+            return make_float4(__uint_as_float((uint32_t)u.x << 16), __uint_as_float((uint32_t)u.y << 16),
+                               __uint_as_float((uint32_t)u.z << 16), __uint_as_float((uint32_t)u.w << 16));
+        }
+        return reinterpret_cast<const float4*>(in + i * (int64_t)dim)[g];
+    };
+    double acc = 0.0;
+    for (int g = lane; g < n4; g += 64) {
+        const float4 v = load4(g);
+        acc += (double)v.x * (double)v.x;
+        acc += (double)v.y * (double)v.y;
+        acc += (double)v.z * (double)v.z;
+        acc += (double)v.w * (double)v.w;
+    }
+    const double n2 = wave_sum(acc);
+    if (!(n2 < 1.0e300)) {   // NaN or Inf somewhere in the row: reject the whole call
+        if (lane == 0) atomicOr(bad, 1);
+        return;
+    }
+    double den = sqrt(n2);
+    if (den < 1e-12) den = 1e-12;
+    const int64_t dst = dst_rows ? dst_rows[i] : row0 + i;
+    for (int g = lane; g < n4; g += 64) {
+        const float4 v = load4(g);
+        float4 y;
+        y.x = (float)((double)v.x / den);
+        y.y = (float)((double)v.y / den);
+        y.z = (float)((double)v.z / den);
+        y.w = (float)((double)v.w / den);
+        if (master) reinterpret_cast<float4*>(master + dst * (int64_t)dim)[g] = y;
+        if (shadow) shadow_store4(shadow, dst, 4 * g, ksteps, scale, y);
+    }
+}
+
+// rebuild the scan copy of rows [row0, row0+n) from the (already normalised) master copy
+__global__ __launch_bounds__(256) void k_reshadow(const float* __restrict__ master, int64_t row0, int64_t n, int dim,
+                                                  _Float16* __restrict__ shadow, int ksteps, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t r = row0 + i;
+    const int n4 = dim >> 2;
+    for (int g = lane; g < n4; g += 64)
+        shadow_store4(shadow, r, 4 * g, ksteps, scale, reinterpret_cast<const float4*>(master + r * (int64_t)dim)[g]);
+}
+
+// out[i] = master[rows[i]]  (collection.get(include=["embeddings"]), compaction)
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ master, const int64_t* __restrict__ rows,
+                                                     int64_t n, int dim, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float4* src = reinterpret_cast<const float4*>(master + rows[i] * (int64_t)dim);
+    float4* dst = reinterpret_cast<float4*>(out + i * (int64_t)dim);
+    for (int g = lane; g < (dim >> 2); g += 64) dst[g] = src[g];
+}
+
+// exact score of one normalised query (float4 view, global or LDS) against one master row, all 64 lanes get it
+template <class Q4>
+__device__ __forceinline__ float exact_score(const float4* __restrict__ row4, Q4 q4, int n4, int lane) {
+    double acc = 0.0;
+    for (int g = lane; g < n4; g += 64) {
+        const float4 c = row4[g];
+        const float4 q = q4[g];
+        acc += (double)q.x * (double)c.x;
+        acc += (double)q.y * (double)c.y;
+        acc += (double)q.z * (double)c.z;
+        acc += (double)q.w * (double)c.w;
+    }
+    return (float)wave_sum(acc);
+}
+
+// K5a. Exact scores of up to QX queries against EVERY row (small problems, huge k, overflow fallback):
+// out[j][r] = score(q_list[j], r), or -inf when the row fails the `where` pre-filter.
+constexpr int QX = 4;
+__global__ __launch_bounds__(256) void k_exact_scores(const float* __restrict__ master, int64_t rows, int dim,
+                                                      const float* __restrict__ qhat, const int32_t* __restrict__ q_list,
+                                                      int nq, const uint32_t* __restrict__ allow,
+                                                      float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* q4 = reinterpret_cast<float4*>(smem);   // [nq][dim/4]
+    const int n4 = dim >> 2;
+    for (int j = 0; j < nq; ++j) {
+        const float4* src = reinterpret_cast<const float4*>(qhat + (int64_t)q_list[j] * dim);
+        for (int g = threadIdx.x; g < n4; g += blockDim.x) q4[j * n4 + g] = src[g];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const bool ok = !allow || ((allow[r >> 5] >> (r & 31)) & 1u);
+        const float4* row4 = reinterpret_cast<const float4*>(master + r * (int64_t)dim);
+        double acc[QX];
+#pragma unroll
+        for (int j = 0; j < QX; ++j) acc[j] = 0.0;
+        if (ok) {
+            for (int g = lane; g < n4; g += 64) {
+                const float4 c = row4[g];
+#pragma unroll
+                for (int j = 0; j < QX; ++j) {
+                    if (j < nq) {
+                        const float4 q = q4[j * n4 + g];
+                        acc[j] += (double)q.x * (double)c.x;
+                        acc[j] += (double)q.y * (double)c.y;
+                        acc[j] += (double)q.z * (double)c.z;
+                        acc[j] += (double)q.w * (double)c.w;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QX; ++j) {
+            if (j < nq) {
+                const float s = (float)wave_sum(acc[j]);
+                if (lane == 0) out[(int64_t)j * rows + r] = ok ? s : -INFINITY;
+            }
+        }
+    }
+}
+
+// rank entries (score desc, row asc) held in LDS and write the best k; all threads of the block call it
+__device__ __forceinline__ void rank_and_write(const float* __restrict__ s, const int64_t* __restrict__ r, int p, int k,
+                                               float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                               int32_t* __restrict__ out_count) {
+    for (int i = threadIdx.x; i < p; i += blockDim.x) {
+        const float si = s[i];
+        const int64_t ri = r[i];
+        int rank = 0;
+        for (int j = 0; j < p; ++j) {
+            const float sj = s[j];
+            rank += (sj > si) || (sj == si && r[j] < ri);
+        }
+        if (rank < k) {
+            out_score[rank] = si;
+            out_row[rank] = ri;
+        }
+    }
+    const int c = p < k ? p : k;
+    for (int i = c + threadIdx.x; i < k; i += blockDim.x) {
+        out_score[i] = -INFINITY;
+        out_row[i] = -1;
+    }
+    if (threadIdx.x == 0) *out_count = c;
+}
+
+// K5b. top-k of a dense score row (one block per listed query): radix select of the k-th largest score, then
+// everything above it plus the LOWEST-row entries equal to it (ties -> ascending row id), then a rank sort.
+// -inf marks rows excluded by the `where` pre-filter; they are never returned.
+constexpr int SELECT_MAX_K = 4096;
+__global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__ scores, int64_t rows,
+                                                       const int32_t* __restrict__ q_list, int k, int64_t row_base,
+                                                       float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                                       int32_t* __restrict__ out_count) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t bc[4];
+    __shared__ float s_s[SELECT_MAX_K];
+    __shared__ int64_t s_r[SELECT_MAX_K];
+    __shared__ int n_sel, n_eq_taken, wave_tot[16];
+    const int j = blockIdx.x;
+    const int q = q_list[j];
+    const float* sc = scores + (int64_t)j * rows;
+    float* o_s = out_score + (int64_t)q * k;
+    int64_t* o_r = out_row + (int64_t)q * k;
+    if (rows == 0 || k == 0) {
+        rank_and_write(s_s, s_r, 0, k, o_s, o_r, out_count + q);
+        return;
+    }
+    const int64_t kk = k < rows ? k : rows;
+    int64_t n_gt;
+    const uint32_t kth = block_kth_largest([&](int64_t i) { return f2key(sc[i]); }, rows, kk, hist, bc, &n_gt);
+    const int need_eq = (int)(kk - n_gt);   // >= 1
+    if (threadIdx.x == 0) {
+        n_sel = 0;
+        n_eq_taken = 0;
+    }
+    __syncthreads();
+    // entries strictly above the k-th key: any order
+    for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) {
+        const float v = sc[i];
+        if (f2key(v) > kth) {
+            const int pos = atomicAdd(&n_sel, 1);
+            s_s[pos] = v;
+            s_r[pos] = row_base + i;
+        }
+    }
+    __syncthreads();
+    // entries equal to the k-th key: in ascending row order until need_eq are taken
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int64_t base = 0; base < rows; base += blockDim.x) {
+        if (n_eq_taken >= need_eq) break;   // uniform: read after the barrier below
+        const int64_t i = base + threadIdx.x;
+        const bool eq = i < rows && f2key(sc[i]) == kth;
+        const unsigned long long m = __ballot(eq);
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int before = n_eq_taken;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        const int my = before + __popcll(m & ((1ull << lane) - 1ull));
+        if (eq && my < need_eq) {
+            s_s[(int)n_gt + my] = sc[i];
+            s_r[(int)n_gt + my] = row_base + i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < nw; ++w) t += wave_tot[w];
+            n_eq_taken += t;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // drop -inf (filtered) entries: they sort last, so count the finite prefix after ranking
+    int p = (int)kk;
+    __shared__ int n_fin;
+    if (threadIdx.x == 0) n_fin = 0;
+    __syncthreads();
+    int loc = 0;
+    for (int i = threadIdx.x; i < p; i += blockDim.x) loc += (s_s[i] > -INFINITY);
+    if (loc) atomicAdd(&n_fin, loc);
+    __syncthreads();
+    const int valid = n_fin;
+    rank_and_write(s_s, s_r, p, valid < k ? valid : k, o_s, o_r, out_count + q);
+    // rank_and_write filled [valid, k) only up to its own k argument; pad the rest
+    for (int i = valid + threadIdx.x; i < k; i += blockDim.x) {
+        o_s[i] = -INFINITY;
+        o_r[i] = -1;
+    }
+}
+
+}  // namespace rdx

@@ -1,0 +1,730 @@
+// rdx_api.hip — host side of librdx: the C-ABI of include/rdx.h, HBM ownership, kernel dispatch.
+// Built for gfx950 only: hipcc --offload-arch=gfx950 -O3 -shared -fPIC rdx_api.hip -o librdx.so
+#include "../../include/rdx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "k_refine.hpp"
+#include "k_rows.hpp"
+#include "k_scan.hpp"
+
+using namespace rdx;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            const int _code = (_e == hipErrorOutOfMemory) ? RDX_ERR_NOMEM : RDX_ERR_HIP;           \
+            return fail(_code, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+        }                                                                                          \
+    } while (0)
+
+#define RDX_TRY(expr)              \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != RDX_OK) return _r; \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return RDX_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            want = need;
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(RDX_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(need) + "): " + hipGetErrorString(e));
+        }
+        bytes = want;
+        return RDX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the index: one corpus shard resident in one GPU's HBM
+// ------------------------------------------------------------------------------------------------
+struct rdx_index {
+    int device = 0;
+    int dim = 0, dim_pad = 0, ksteps = 0, scale_log2 = 0;
+    int n_cu = 256;
+    int64_t rows = 0, cap = 0;   // cap is a multiple of 256
+    float* master = nullptr;     // [cap][dim]
+    _Float16* shadow = nullptr;  // [cap/256][ksteps][256][64]
+    hipStream_t own_stream = nullptr;
+    std::mutex mu;
+
+    // options
+    int force_exact = 0, force_fast = 0, profile = 0;
+    int sample_div = 32;
+    int64_t cand_cap = 0;   // 0 = automatic
+
+    // scratch (grow-only; never allocated inside a warmed-up search)
+    DevBuf staging, qraw, qhat, qshadow, tau, cnt, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
+        o_count, mask, ids;
+    hipEvent_t ev[8] = {};
+    bool ev_ok = false;
+    rdx_search_stats stats = {};
+
+    float scale() const { return std::ldexp(1.0f, scale_log2); }
+    float two_e() const { return 2.0f * (1.0e-3f + 2.5e-7f * (float)dim_pad); }   // see DESIGN.md "error bound"
+};
+
+static size_t shadow_bytes(const rdx_index* h, int64_t cap) { return (size_t)cap * h->dim_pad * 2; }
+
+static int set_device(const rdx_index* h) {
+    HIP_TRY(hipSetDevice(h->device));
+    return RDX_OK;
+}
+
+static int grow(rdx_index* h, int64_t need_rows) {
+    if (need_rows <= h->cap) return RDX_OK;
+    int64_t ncap = std::max<int64_t>(need_rows, h->cap + h->cap / 2);
+    ncap = (ncap + 255) / 256 * 256;
+    float* nm = nullptr;
+    _Float16* ns = nullptr;
+    hipError_t e = hipMalloc((void**)&nm, (size_t)ncap * h->dim * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ns, shadow_bytes(h, ncap));
+    if (e != hipSuccess && ncap > (need_rows + 255) / 256 * 256) {   // retry without head-room
+        if (nm) (void)hipFree(nm);
+        nm = nullptr;
+        ncap = (need_rows + 255) / 256 * 256;
+        e = hipMalloc((void**)&nm, (size_t)ncap * h->dim * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&ns, shadow_bytes(h, ncap));
+    }
+    if (e != hipSuccess) {
+        if (nm) (void)hipFree(nm);
+        return fail(RDX_ERR_NOMEM, std::string("growing index to ") + std::to_string(ncap) + " rows: " + hipGetErrorString(e));
+    }
+    hipStream_t st = h->own_stream;
+    HIP_TRY(hipMemsetAsync(ns, 0, shadow_bytes(h, ncap), st));
+    if (h->rows > 0) {
+        HIP_TRY(hipMemcpyAsync(nm, h->master, (size_t)h->rows * h->dim * 4, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ns, h->shadow, shadow_bytes(h, h->cap), hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h->master) (void)hipFree(h->master);
+    if (h->shadow) (void)hipFree(h->shadow);
+    h->master = nm;
+    h->shadow = ns;
+    h->cap = ncap;
+    return RDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// library / lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" int rdx_version(void) { return RDX_ABI_VERSION; }
+extern "C" const char* rdx_last_error(void) { return g_err.c_str(); }
+
+extern "C" int rdx_device_count(int* n) {
+    if (!n) return fail(RDX_ERR_INVALID, "rdx_device_count: null pointer");
+    HIP_TRY(hipGetDeviceCount(n));
+    return RDX_OK;
+}
+
+static int check_dim(int dim) {
+    if (dim <= 0 || dim % 4 != 0 || dim > MAX_DIM)
+        return fail(RDX_ERR_INVALID, "dim must be a positive multiple of 4, at most " + std::to_string(MAX_DIM) + " (got " +
+                                         std::to_string(dim) + ")");
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_create(int device, int dim, rdx_index** out) {
+    if (!out) return fail(RDX_ERR_INVALID, "rdx_index_create: null out pointer");
+    RDX_TRY(check_dim(dim));
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(RDX_ERR_INVALID, "device " + std::to_string(device) + " out of range (" + std::to_string(ndev) + " visible)");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(RDX_ERR_STATE, std::string("librdx is built for gfx950 (MI355X) only; device reports ") + prop.gcnArchName);
+    rdx_index* h = new rdx_index();
+    h->device = device;
+    h->dim = dim;
+    h->dim_pad = (dim + 63) / 64 * 64;
+    h->ksteps = h->dim_pad / 64;
+    h->scale_log2 = (int)std::lround(std::log2(std::sqrt((double)dim)));
+    h->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(RDX_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_destroy(rdx_index* h) {
+    if (!h) return RDX_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->own_stream);
+    if (h->master) (void)hipFree(h->master);
+    if (h->shadow) (void)hipFree(h->shadow);
+    for (DevBuf* b : {&h->staging, &h->qraw, &h->qhat, &h->qshadow, &h->tau, &h->cnt, &h->cand, &h->setmax, &h->exact_list,
+                      &h->iota, &h->dense, &h->ctr, &h->bad, &h->o_score, &h->o_row, &h->o_count, &h->mask, &h->ids})
+        b->release();
+    if (h->ev_ok)
+        for (auto& e : h->ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_dim(const rdx_index* h, int* dim) {
+    if (!h || !dim) return fail(RDX_ERR_INVALID, "rdx_index_dim: null pointer");
+    *dim = h->dim;
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_count(const rdx_index* h, int64_t* rows) {
+    if (!h || !rows) return fail(RDX_ERR_INVALID, "rdx_index_count: null pointer");
+    *rows = h->rows;
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_reserve(rdx_index* h, int64_t rows) {
+    if (!h || rows < 0) return fail(RDX_ERR_INVALID, "rdx_index_reserve: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(set_device(h));
+    return grow(h, rows);
+}
+
+extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t value) {
+    if (!h || !name) return fail(RDX_ERR_INVALID, "rdx_index_set_option: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const std::string n(name);
+    if (n == "force_exact") h->force_exact = value != 0;
+    else if (n == "force_fast") h->force_fast = value != 0;
+    else if (n == "profile") h->profile = value != 0;
+    else if (n == "sample_div") {
+        if (value < 1) return fail(RDX_ERR_INVALID, "sample_div must be >= 1");
+        h->sample_div = (int)std::min<int64_t>(value, 1 << 20);
+    } else if (n == "cand_cap") {
+        if (value != 0 && value < 64) return fail(RDX_ERR_INVALID, "cand_cap must be 0 (auto) or >= 64");
+        h->cand_cap = value;
+    } else
+        return fail(RDX_ERR_INVALID, "unknown option '" + n + "'");
+    return RDX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ingest
+// ------------------------------------------------------------------------------------------------
+static const int64_t STAGE_ROWS = 32768;
+
+// normalise n rows (host or device, fp32 or bf16) into master/shadow at dst rows (row0.. or dst_ids)
+static int ingest(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int space, int64_t row0, const int64_t* d_dst_ids) {
+    hipStream_t st = h->own_stream;
+    const size_t esz = is_bf16 ? 2 : 4;
+    RDX_TRY(h->bad.ensure(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->bad.p, 0, sizeof(int), st));
+    for (int64_t off = 0; off < n; off += STAGE_ROWS) {
+        const int64_t m = std::min(STAGE_ROWS, n - off);
+        const char* src = reinterpret_cast<const char*>(rows) + (size_t)off * h->dim * esz;
+        if (space == RDX_HOST) {
+            RDX_TRY(h->staging.ensure((size_t)STAGE_ROWS * h->dim * 4));
+            HIP_TRY(hipMemcpyAsync(h->staging.p, src, (size_t)m * h->dim * esz, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));   // pageable source: keep the copy ordered with the caller's buffer
+            src = h->staging.as<char>();
+        }
+        const int grid = (int)((m + 3) / 4);
+        hipLaunchKernelGGL(k_normalize, dim3(grid), dim3(256), 0, st, is_bf16 ? nullptr : (const float*)src,
+                           is_bf16 ? (const uint16_t*)src : nullptr, m, h->dim, d_dst_ids ? d_dst_ids + off : nullptr,
+                           row0 + off, h->master, h->shadow, h->ksteps, h->scale(), h->bad.as<int>());
+        HIP_TRY(hipGetLastError());
+        if (space == RDX_HOST) HIP_TRY(hipStreamSynchronize(st));   // staging is reused by the next chunk
+    }
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad) return fail(RDX_ERR_INVALID, "embeddings contain NaN or Inf");
+    return RDX_OK;
+}
+
+static int add_impl(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int space) {
+    if (!h || (n > 0 && !rows) || n < 0) return fail(RDX_ERR_INVALID, "rdx_index_add: bad argument");
+    if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    if (n == 0) return RDX_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(set_device(h));
+    RDX_TRY(grow(h, h->rows + n));
+    RDX_TRY(ingest(h, rows, is_bf16, n, space, h->rows, nullptr));
+    h->rows += n;
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_add(rdx_index* h, const float* rows, int64_t n, int space) { return add_impl(h, rows, false, n, space); }
+extern "C" int rdx_index_add_bf16(rdx_index* h, const uint16_t* rows, int64_t n, int space) {
+    return add_impl(h, rows, true, n, space);
+}
+
+// copy a host or device int64 id list to the device scratch `ids`, validating on the host when possible
+static int stage_ids(rdx_index* h, const int64_t* ids, int64_t n, int space, const int64_t** d_ids) {
+    hipStream_t st = h->own_stream;
+    std::vector<int64_t> tmp;
+    const int64_t* host_ids = ids;
+    if (space == RDX_DEVICE) {
+        tmp.resize((size_t)n);
+        HIP_TRY(hipMemcpy(tmp.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost));
+        host_ids = tmp.data();
+    }
+    for (int64_t i = 0; i < n; ++i)
+        if (host_ids[i] < 0 || host_ids[i] >= h->rows)
+            return fail(RDX_ERR_INVALID, "row id " + std::to_string(host_ids[i]) + " out of range [0, " + std::to_string(h->rows) + ")");
+    if (space == RDX_DEVICE) {
+        *d_ids = ids;
+        return RDX_OK;
+    }
+    RDX_TRY(h->ids.ensure((size_t)n * 8));
+    HIP_TRY(hipMemcpyAsync(h->ids.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *d_ids = h->ids.as<int64_t>();
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_update(rdx_index* h, const int64_t* row_ids, const float* rows, int64_t n, int space) {
+    if (!h || n < 0 || (n > 0 && (!row_ids || !rows))) return fail(RDX_ERR_INVALID, "rdx_index_update: bad argument");
+    if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    if (n == 0) return RDX_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(set_device(h));
+    const int64_t* d_ids = nullptr;
+    RDX_TRY(stage_ids(h, row_ids, n, space, &d_ids));
+    return ingest(h, rows, false, n, space, 0, d_ids);
+}
+
+extern "C" int rdx_index_get(rdx_index* h, const int64_t* row_ids, int64_t n, float* out, int space) {
+    if (!h || n < 0 || (n > 0 && (!row_ids || !out))) return fail(RDX_ERR_INVALID, "rdx_index_get: bad argument");
+    if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    if (n == 0) return RDX_OK;
+    std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(set_device(h));
+    hipStream_t st = h->own_stream;
+    const int64_t* d_ids = nullptr;
+    RDX_TRY(stage_ids(h, row_ids, n, space, &d_ids));
+    for (int64_t off = 0; off < n; off += STAGE_ROWS) {
+        const int64_t m = std::min(STAGE_ROWS, n - off);
+        float* dst = out + (size_t)off * h->dim;
+        if (space == RDX_HOST) {
+            RDX_TRY(h->staging.ensure((size_t)STAGE_ROWS * h->dim * 4));
+            dst = h->staging.as<float>();
+        }
+        hipLaunchKernelGGL(k_gather_rows, dim3((int)((m + 3) / 4)), dim3(256), 0, st, h->master, d_ids + off, m, h->dim, dst);
+        HIP_TRY(hipGetLastError());
+        if (space == RDX_HOST) {
+            HIP_TRY(hipMemcpyAsync(out + (size_t)off * h->dim, dst, (size_t)m * h->dim * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep) {
+    if (!h || n_keep < 0 || (n_keep > 0 && !keep)) return fail(RDX_ERR_INVALID, "rdx_index_compact: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(set_device(h));
+    for (int64_t i = 0; i < n_keep; ++i) {
+        if (keep[i] < 0 || keep[i] >= h->rows) return fail(RDX_ERR_INVALID, "compact: row id out of range");
+        if (i > 0 && keep[i] <= keep[i - 1]) return fail(RDX_ERR_INVALID, "compact: keep list must be strictly ascending");
+    }
+    hipStream_t st = h->own_stream;
+    const int64_t ncap = std::max<int64_t>(256, (n_keep + 255) / 256 * 256);
+    float* nm = nullptr;
+    _Float16* ns = nullptr;
+    HIP_TRY(hipMalloc((void**)&nm, (size_t)ncap * h->dim * 4));
+    hipError_t e = hipMalloc((void**)&ns, shadow_bytes(h, ncap));
+    if (e != hipSuccess) {
+        (void)hipFree(nm);
+        return fail(RDX_ERR_NOMEM, std::string("compact: ") + hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemsetAsync(ns, 0, shadow_bytes(h, ncap), st));
+    if (n_keep > 0) {
+        RDX_TRY(h->ids.ensure((size_t)n_keep * 8));
+        HIP_TRY(hipMemcpyAsync(h->ids.p, keep, (size_t)n_keep * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_gather_rows, dim3((int)((n_keep + 3) / 4)), dim3(256), 0, st, h->master, h->ids.as<int64_t>(), n_keep,
+                           h->dim, nm);
+        hipLaunchKernelGGL(k_reshadow, dim3((int)((n_keep + 3) / 4)), dim3(256), 0, st, nm, (int64_t)0, n_keep, h->dim, ns,
+                           h->ksteps, h->scale());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h->master) (void)hipFree(h->master);
+    if (h->shadow) (void)hipFree(h->shadow);
+    h->master = nm;
+    h->shadow = ns;
+    h->cap = ncap;
+    h->rows = n_keep;
+    return RDX_OK;
+}
+
+extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space, void* stream) {
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(RDX_ERR_INVALID, "rdx_l2_normalize: bad argument");
+    RDX_TRY(check_dim(dim));
+    if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    if (n == 0) return RDX_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const float* d_in = in;
+    float* d_out = out;
+    DevBuf bi, bo, bad;
+    RDX_TRY(bad.ensure(sizeof(int)));
+    if (space == RDX_HOST) {
+        RDX_TRY(bi.ensure((size_t)n * dim * 4));
+        RDX_TRY(bo.ensure((size_t)n * dim * 4));
+        HIP_TRY(hipMemcpyAsync(bi.p, in, (size_t)n * dim * 4, hipMemcpyHostToDevice, st));
+        d_in = bi.as<float>();
+        d_out = bo.as<float>();
+    }
+    HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_normalize, dim3((int)((n + 3) / 4)), dim3(256), 0, st, d_in, (const uint16_t*)nullptr, n, dim,
+                       (const int64_t*)nullptr, (int64_t)0, d_out, (_Float16*)nullptr, 0, 1.0f, bad.as<int>());
+    HIP_TRY(hipGetLastError());
+    int rc = RDX_OK;
+    if (space == RDX_HOST) {
+        int b = 0;
+        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * dim * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&b, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (b) rc = fail(RDX_ERR_INVALID, "embeddings contain NaN or Inf");
+    } else {
+        HIP_TRY(hipStreamSynchronize(st));   // scratch below is freed on return
+    }
+    bi.release();
+    bo.release();
+    bad.release();
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------
+template <int BN, int EPI>
+static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t st) {
+    const size_t lds = 2 * (size_t)(KSTEP_BYTES + BN * BK * 2);
+    if (p.allow) {
+        auto kern = k_scan<BN, EPI, true>;
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+    } else {
+        auto kern = k_scan<BN, EPI, false>;
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
+template <int EPI>
+static int launch_scan_bn(rdx_index* h, int bn, const ScanParams& p, int grid, hipStream_t st) {
+    if (bn == 64) return launch_scan<64, EPI>(h, p, grid, st);
+    if (bn == 128) return launch_scan<128, EPI>(h, p, grid, st);
+    return launch_scan<256, EPI>(h, p, grid, st);
+}
+
+static const int K_FAST_MAX = 256;   // larger k goes through the exact full scan
+
+// exact full scan for the queries listed in d_list[0..n_list)
+static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, const uint32_t* d_allow, float* d_score,
+                     int64_t* d_row, int32_t* d_count, hipStream_t st) {
+    RDX_TRY(h->dense.ensure((size_t)QX * std::max<int64_t>(h->rows, 1) * 4));
+    const int grid_rows = (int)std::min<int64_t>((h->rows + 3) / 4, (int64_t)h->n_cu * 8);
+    for (int j0 = 0; j0 < n_list; j0 += QX) {
+        const int nq = std::min(QX, n_list - j0);
+        if (h->rows > 0) {
+            hipLaunchKernelGGL(k_exact_scores, dim3(std::max(grid_rows, 1)), dim3(256), (size_t)nq * h->dim * 4, st, h->master,
+                               h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>());
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_select_dense, dim3(nq), dim3(1024), 0, st, h->dense.as<float>(), h->rows, d_list + j0, k, (int64_t)0,
+                           d_score, d_row, d_count);
+        HIP_TRY(hipGetLastError());
+    }
+    return RDX_OK;
+}
+
+static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k, const uint32_t* d_allow, float* d_score,
+                        int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats) {
+    const int nq_pad = (int)((nq + 255) / 256 * 256);
+    const bool prof = h->profile != 0;
+    auto mark = [&](int i) {
+        if (prof) (void)hipEventRecord(h->ev[i], st);
+    };
+    // K1 on the queries: qhat (fp32, exact re-score) + tiled fp16 copy (scan)
+    RDX_TRY(h->qhat.ensure((size_t)nq_pad * h->dim * 4));
+    RDX_TRY(h->qshadow.ensure((size_t)nq_pad * h->dim_pad * 2));
+    RDX_TRY(h->bad.ensure(sizeof(int)));
+    RDX_TRY(h->ctr.ensure(sizeof(RefineCounters)));
+    RDX_TRY(h->exact_list.ensure((size_t)nq_pad * 4));
+    mark(0);
+    HIP_TRY(hipMemsetAsync(h->bad.p, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(h->ctr.p, 0, sizeof(RefineCounters), st));
+    if (nq != nq_pad || h->dim != h->dim_pad) HIP_TRY(hipMemsetAsync(h->qshadow.p, 0, (size_t)nq_pad * h->dim_pad * 2, st));
+    hipLaunchKernelGGL(k_normalize, dim3((int)((nq + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
+                       (const int64_t*)nullptr, (int64_t)0, h->qhat.as<float>(), h->qshadow.as<_Float16>(), h->ksteps, h->scale(),
+                       h->bad.as<int>());
+    HIP_TRY(hipGetLastError());
+    mark(1);
+
+    // small problems and huge k are served by the exact full scan alone (one fp32 read of the corpus)
+    const bool small = h->rows < 2048 || nq * h->rows <= (int64_t)1 << 22;
+    const bool exact_only = h->force_exact || k > K_FAST_MAX || k == 0 || h->rows < 1 || (small && !h->force_fast);
+    int n_exact = 0;
+    RefineCounters ctr = {};
+    int64_t sample_rows = 0;
+    if (exact_only) {
+        for (int i = 2; i <= 5; ++i) mark(i);
+        RDX_TRY(h->iota.ensure((size_t)nq_pad * 4));
+        std::vector<int32_t> io((size_t)nq);
+        for (int64_t i = 0; i < nq; ++i) io[(size_t)i] = (int32_t)i;
+        HIP_TRY(hipMemcpyAsync(h->iota.p, io.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st));
+        n_exact = (int)nq;
+    } else {
+        const int bn = nq <= 64 ? 64 : (nq <= 128 ? 128 : 256);
+        const int nqt = (int)((nq + bn - 1) / bn);
+        const int grid = std::max(8, h->n_cu / 8 * 8);
+        const int wpx = grid / 8;
+        if (nqt > wpx) return fail(RDX_ERR_STATE, "internal: query chunk larger than one scan launch");
+        const int G = wpx / nqt;
+        const int n_streams = 8 * G;
+        const int wm = 8 / (bn / 64);
+        const int n_sets = n_streams * wm * SETS_PER_WAVE;
+        const int64_t n_tiles = (h->rows + 255) / 256;
+        // bootstrap sample: every div-th tile, at least ~max(64k, 8192) rows when the corpus has them
+        const int64_t want_rows = std::max<int64_t>(64 * (int64_t)k, 8192);
+        int div = (int)std::max<int64_t>(1, std::min<int64_t>(h->sample_div, h->rows / want_rows));
+        sample_rows = (n_tiles + div - 1) / div * 256;
+        uint32_t cap = (uint32_t)(h->cand_cap ? h->cand_cap : std::max<int64_t>(2048, 128 * (int64_t)k));
+        RDX_TRY(h->tau.ensure((size_t)nq_pad * 4));
+        RDX_TRY(h->cnt.ensure((size_t)nq_pad * 4));
+        RDX_TRY(h->cand.ensure((size_t)nq_pad * cap * 8));
+        RDX_TRY(h->setmax.ensure((size_t)nq_pad * n_sets * 4));
+        HIP_TRY(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, st));
+
+        ScanParams p = {};
+        p.shadow = h->shadow;
+        p.qshadow = h->qshadow.as<_Float16>();
+        p.ksteps = h->ksteps;
+        p.rows = h->rows;
+        p.n_tiles = n_tiles;
+        p.nqt = nqt;
+        p.nq_pad = nq_pad;
+        p.allow = d_allow;
+        p.setmax = h->setmax.as<float>();
+        p.n_sets = n_sets;
+        p.tau = h->tau.as<float>();
+        p.cnt = h->cnt.as<uint32_t>();
+        p.cand = h->cand.as<uint2>();
+        p.cap = cap;
+        p.inv_scale2 = std::ldexp(1.0f, -2 * h->scale_log2);
+
+        p.tile_stride = div;
+        RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn, p, grid, st));
+        mark(2);
+        hipLaunchKernelGGL(k_tau, dim3(nq_pad), dim3(256), 0, st, h->setmax.as<float>(), n_sets, k,
+                           h->two_e() * std::ldexp(1.0f, 2 * h->scale_log2), (int)nq, h->tau.as<float>());
+        HIP_TRY(hipGetLastError());
+        mark(3);
+        p.tile_stride = 1;
+        RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, p, grid, st));
+        mark(4);
+        hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(256), 0, st, h->cand.as<uint2>(), h->cnt.as<uint32_t>(), cap, k, h->two_e(),
+                           h->qhat.as<float>(), h->master, h->dim, (int64_t)0, d_score, d_row, d_count,
+                           h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
+        HIP_TRY(hipGetLastError());
+        mark(5);
+        HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n_exact = ctr.n_exact;
+        if (n_exact > 0) RDX_TRY(run_exact(h, h->exact_list.as<int32_t>(), n_exact, k, d_allow, d_score, d_row, d_count, st));
+        acc_stats->scan_main_launch_rows = h->rows;
+        acc_stats->scan_main_launch_queries = nq;
+    }
+    mark(6);
+    int bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad) return fail(RDX_ERR_INVALID, "query embeddings contain NaN or Inf");
+
+    acc_stats->sample_rows += exact_only ? 0 : sample_rows;
+    acc_stats->emitted += (int64_t)ctr.emitted;
+    acc_stats->rescored += (int64_t)ctr.rescored;
+    acc_stats->exact_queries += n_exact;
+    acc_stats->path = exact_only ? 1 : 0;
+    if (prof) {
+        float ms[6] = {};
+        for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]);
+        acc_stats->profiled = 1;
+        acc_stats->ms_normalize += ms[0];
+        acc_stats->ms_scan_sample += ms[1];
+        acc_stats->ms_tau += ms[2];
+        acc_stats->ms_scan_main += ms[3];
+        acc_stats->ms_refine += ms[4];
+        acc_stats->ms_exact += ms[5];
+        float tot = 0;
+        (void)hipEventElapsedTime(&tot, h->ev[0], h->ev[6]);
+        acc_stats->ms_total += tot;
+    }
+    return RDX_OK;
+}
+
+extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k, const uint32_t* allow_bits, float* out_score,
+                          int64_t* out_row, int32_t* out_count, int space, void* stream) {
+    if (!h) return fail(RDX_ERR_INVALID, "rdx_search: null index");
+    if (nq < 0 || k < 0) return fail(RDX_ERR_INVALID, "rdx_search: nq and k must be >= 0");
+    if (k > SELECT_MAX_K) return fail(RDX_ERR_INVALID, "rdx_search: k larger than " + std::to_string(SELECT_MAX_K) + " is not supported");
+    if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    if (nq == 0) return RDX_OK;
+    if (!queries || !out_count || (k > 0 && (!out_score || !out_row))) return fail(RDX_ERR_INVALID, "rdx_search: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(set_device(h));
+    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    if (h->profile && !h->ev_ok) {
+        for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+        h->ev_ok = true;
+    }
+    rdx_search_stats s = {};
+    s.nq = nq;
+    s.k = k;
+    s.rows = h->rows;
+
+    const uint32_t* d_allow = allow_bits;
+    const size_t mask_words = (size_t)((h->rows + 31) / 32);
+    if (allow_bits && space == RDX_HOST && mask_words > 0) {
+        // pad to whole 256-row tiles so the scan may read the word of any block it touches
+        const size_t pad_words = (size_t)((h->rows + 255) / 256 * 8);
+        RDX_TRY(h->mask.ensure(pad_words * 4));
+        HIP_TRY(hipMemsetAsync(h->mask.p, 0, pad_words * 4, st));
+        HIP_TRY(hipMemcpyAsync(h->mask.p, allow_bits, mask_words * 4, hipMemcpyHostToDevice, st));
+        d_allow = h->mask.as<uint32_t>();
+    }
+    const int64_t CHUNK = 4096;   // queries per pipeline pass (<= 256 * WGs per XCD)
+    const int kk = std::max(k, 1);
+    for (int64_t q0 = 0; q0 < nq; q0 += CHUNK) {
+        const int64_t m = std::min(CHUNK, nq - q0);
+        const float* d_q = queries + (size_t)q0 * h->dim;
+        float* d_s = out_score ? out_score + (size_t)q0 * k : nullptr;
+        int64_t* d_r = out_row ? out_row + (size_t)q0 * k : nullptr;
+        int32_t* d_c = out_count + q0;
+        if (space == RDX_HOST) {
+            RDX_TRY(h->qraw.ensure((size_t)m * h->dim * 4));
+            RDX_TRY(h->o_score.ensure((size_t)m * kk * 4));
+            RDX_TRY(h->o_row.ensure((size_t)m * kk * 8));
+            RDX_TRY(h->o_count.ensure((size_t)m * 4));
+            HIP_TRY(hipMemcpyAsync(h->qraw.p, d_q, (size_t)m * h->dim * 4, hipMemcpyHostToDevice, st));
+            d_q = h->qraw.as<float>();
+            d_s = h->o_score.as<float>();
+            d_r = h->o_row.as<int64_t>();
+            d_c = h->o_count.as<int32_t>();
+        }
+        RDX_TRY(search_chunk(h, d_q, m, k, d_allow, d_s, d_r, d_c, st, &s));
+        if (space == RDX_HOST) {
+            if (k > 0) {
+                HIP_TRY(hipMemcpyAsync(out_score + (size_t)q0 * k, d_s, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(out_row + (size_t)q0 * k, d_r, (size_t)m * k * 8, hipMemcpyDeviceToHost, st));
+            }
+            HIP_TRY(hipMemcpyAsync(out_count + q0, d_c, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+    h->stats = s;
+    return RDX_OK;
+}
+
+extern "C" int rdx_search_last_stats(rdx_index* h, rdx_search_stats* out) {
+    if (!h || !out) return fail(RDX_ERR_INVALID, "rdx_search_last_stats: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *out = h->stats;
+    return RDX_OK;
+}
+
+extern "C" int rdx_merge_topk(int device, const float* part_score, const int64_t* part_row, const int32_t* part_count, int n_parts,
+                              int64_t nq, int k, float* out_score, int64_t* out_row, int32_t* out_count, int space, void* stream) {
+    if (n_parts < 1 || n_parts > 64 || nq < 0 || k < 0) return fail(RDX_ERR_INVALID, "rdx_merge_topk: bad shape");
+    if ((int64_t)n_parts * k > MERGE_MAX) return fail(RDX_ERR_INVALID, "rdx_merge_topk: n_parts * k exceeds " + std::to_string(MERGE_MAX));
+    if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    if (nq == 0) return RDX_OK;
+    if (!part_count || !out_count || (k > 0 && (!part_score || !part_row || !out_score || !out_row)))
+        return fail(RDX_ERR_INVALID, "rdx_merge_topk: null pointer");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t np = (size_t)n_parts * nq;
+    const int kk = std::max(k, 1);
+    DevBuf ps, pr, pc, os, orow, oc;
+    const float* d_ps = part_score;
+    const int64_t* d_pr = part_row;
+    const int32_t* d_pc = part_count;
+    float* d_os = out_score;
+    int64_t* d_or = out_row;
+    int32_t* d_oc = out_count;
+    if (space == RDX_HOST) {
+        RDX_TRY(ps.ensure(np * kk * 4));
+        RDX_TRY(pr.ensure(np * kk * 8));
+        RDX_TRY(pc.ensure(np * 4));
+        RDX_TRY(os.ensure((size_t)nq * kk * 4));
+        RDX_TRY(orow.ensure((size_t)nq * kk * 8));
+        RDX_TRY(oc.ensure((size_t)nq * 4));
+        if (k > 0) {
+            HIP_TRY(hipMemcpyAsync(ps.p, part_score, np * k * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(pr.p, part_row, np * k * 8, hipMemcpyHostToDevice, st));
+        }
+        HIP_TRY(hipMemcpyAsync(pc.p, part_count, np * 4, hipMemcpyHostToDevice, st));
+        d_ps = ps.as<float>();
+        d_pr = pr.as<int64_t>();
+        d_pc = pc.as<int32_t>();
+        d_os = os.as<float>();
+        d_or = orow.as<int64_t>();
+        d_oc = oc.as<int32_t>();
+    }
+    hipLaunchKernelGGL(k_merge, dim3((int)nq), dim3(256), 0, st, d_ps, d_pr, d_pc, n_parts, nq, k, d_os, d_or, d_oc);
+    HIP_TRY(hipGetLastError());
+    if (space == RDX_HOST) {
+        if (k > 0) {
+            HIP_TRY(hipMemcpyAsync(out_score, d_os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_row, d_or, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipMemcpyAsync(out_count, d_oc, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (DevBuf* b : {&ps, &pr, &pc, &os, &orow, &oc}) b->release();
+    }
+    return RDX_OK;
+}

@@ -1,0 +1,159 @@
+"""HipIndex — one corpus shard in one MI355X's HBM, driven through the C-ABI (include/rdx.h).
+
+numpy arrays cross as host pointers (RDX_HOST, synchronous); torch CUDA tensors cross as device
+pointers (RDX_DEVICE) on the current torch stream. No arithmetic happens in this file.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _np_ptr(a: np.ndarray):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class HipIndex:
+    def __init__(self, dim: int, device: int = 0):
+        self._lib = L.load(require_gpu=True)
+        self._h = ctypes.c_void_p()
+        L.check(self._lib.rdx_index_create(int(device), int(dim), ctypes.byref(self._h)))
+        self.dim = int(dim)
+        self.device = int(device)
+
+    # ---- lifecycle -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.rdx_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        n = ctypes.c_int64(0)
+        L.check(self._lib.rdx_index_count(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def reserve(self, rows: int):
+        L.check(self._lib.rdx_index_reserve(self._h, int(rows)))
+
+    def set_option(self, name: str, value: int):
+        L.check(self._lib.rdx_index_set_option(self._h, name.encode(), int(value)))
+
+    # ---- helpers ----------------------------------------------------------------------------
+    def _rows_arg(self, x, dtype=np.float32):
+        """-> (pointer, n, space, keepalive)"""
+        import torch
+        if isinstance(x, torch.Tensor):
+            want = torch.float32 if dtype == np.float32 else torch.bfloat16
+            if x.dtype != want or x.dim() != 2 or x.shape[1] != self.dim:
+                raise ValueError(f"expected a [n][{self.dim}] {want} tensor, got {tuple(x.shape)} {x.dtype}")
+            if x.is_cuda:
+                if x.device.index != self.device:
+                    raise ValueError("tensor lives on another device than the index")
+                x = x.contiguous()
+                torch.cuda.current_stream(x.device).synchronize()  # ingest runs on the index's own stream
+                return ctypes.c_void_p(x.data_ptr()), x.shape[0], L.RDX_DEVICE, x
+            x = x.numpy() if dtype == np.float32 else x.view(torch.uint16).numpy()
+        a = np.ascontiguousarray(x, dtype=dtype if dtype == np.float32 else np.uint16)
+        if a.ndim != 2 or a.shape[1] != self.dim:
+            raise ValueError(f"expected [n][{self.dim}] embeddings, got shape {a.shape}")
+        return _np_ptr(a), a.shape[0], L.RDX_HOST, a
+
+    # ---- ingest -----------------------------------------------------------------------------
+    def add(self, rows):
+        p, n, space, keep = self._rows_arg(rows)
+        L.check(self._lib.rdx_index_add(self._h, p, n, space))
+
+    def add_bf16(self, rows):
+        p, n, space, keep = self._rows_arg(rows, dtype=np.uint16)
+        L.check(self._lib.rdx_index_add_bf16(self._h, p, n, space))
+
+    def update(self, row_ids, rows):
+        ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        a = np.ascontiguousarray(rows, dtype=np.float32)
+        if a.ndim != 2 or a.shape != (ids.shape[0], self.dim):
+            raise ValueError("update: rows must be [len(row_ids)][dim]")
+        L.check(self._lib.rdx_index_update(self._h, _np_ptr(ids), _np_ptr(a), ids.shape[0], L.RDX_HOST))
+
+    def get(self, row_ids) -> np.ndarray:
+        ids = np.ascontiguousarray(row_ids, dtype=np.int64)
+        out = np.empty((ids.shape[0], self.dim), dtype=np.float32)
+        L.check(self._lib.rdx_index_get(self._h, _np_ptr(ids), ids.shape[0], _np_ptr(out), L.RDX_HOST))
+        return out
+
+    def compact(self, keep_rows):
+        keep = np.ascontiguousarray(keep_rows, dtype=np.int64)
+        L.check(self._lib.rdx_index_compact(self._h, _np_ptr(keep), keep.shape[0]))
+
+    # ---- search -----------------------------------------------------------------------------
+    def search(self, queries, k: int, allow_bits: Optional[np.ndarray] = None
+               ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Host in / host out. Returns (score f32[nq,k], row i64[nq,k], count i32[nq])."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected [nq][{self.dim}] query embeddings, got shape {q.shape}")
+        nq = q.shape[0]
+        sc = np.empty((nq, k), dtype=np.float32)
+        ro = np.empty((nq, k), dtype=np.int64)
+        cn = np.zeros((nq,), dtype=np.int32)
+        mp = None
+        if allow_bits is not None:
+            allow_bits = np.ascontiguousarray(allow_bits, dtype=np.uint32)
+            if allow_bits.shape[0] != (len(self) + 31) // 32:
+                raise ValueError("allow_bits must hold ceil(count/32) words")
+            mp = _np_ptr(allow_bits)
+        L.check(self._lib.rdx_search(self._h, _np_ptr(q), nq, int(k), mp, _np_ptr(sc), _np_ptr(ro), _np_ptr(cn),
+                                     L.RDX_HOST, None))
+        return sc, ro, cn
+
+    def search_device(self, queries, k: int, out_score, out_row, out_count, allow_bits=None):
+        """torch CUDA tensors in/out, enqueued on the current torch stream (no host copies)."""
+        import torch
+        nq = queries.shape[0]
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        assert out_score.shape == (nq, k) and out_score.dtype == torch.float32 and out_score.is_contiguous()
+        assert out_row.shape == (nq, k) and out_row.dtype == torch.int64 and out_row.is_contiguous()
+        assert out_count.shape == (nq,) and out_count.dtype == torch.int32
+        stream = torch.cuda.current_stream(queries.device).cuda_stream
+        mp = ctypes.c_void_p(allow_bits.data_ptr()) if allow_bits is not None else None
+        L.check(self._lib.rdx_search(self._h, ctypes.c_void_p(queries.data_ptr()), nq, int(k), mp,
+                                     ctypes.c_void_p(out_score.data_ptr()), ctypes.c_void_p(out_row.data_ptr()),
+                                     ctypes.c_void_p(out_count.data_ptr()), L.RDX_DEVICE, ctypes.c_void_p(stream)))
+
+    def last_stats(self) -> dict:
+        s = L.SearchStats()
+        L.check(self._lib.rdx_search_last_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+
+def l2_normalize(x: np.ndarray, device: int = 0) -> np.ndarray:
+    lib = L.load(require_gpu=True)
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if a.ndim != 2:
+        raise ValueError("l2_normalize wants [n][dim]")
+    out = np.empty_like(a)
+    L.check(lib.rdx_l2_normalize(device, _np_ptr(a), a.shape[0], a.shape[1], _np_ptr(out), L.RDX_HOST, None))
+    return out
+
+
+def merge_topk(part_score: np.ndarray, part_row: np.ndarray, part_count: np.ndarray, k: int, device: int = 0):
+    lib = L.load(require_gpu=True)
+    ps = np.ascontiguousarray(part_score, dtype=np.float32)
+    pr = np.ascontiguousarray(part_row, dtype=np.int64)
+    pc = np.ascontiguousarray(part_count, dtype=np.int32)
+    P, nq = pc.shape
+    sc = np.empty((nq, k), dtype=np.float32)
+    ro = np.empty((nq, k), dtype=np.int64)
+    cn = np.empty((nq,), dtype=np.int32)
+    L.check(lib.rdx_merge_topk(device, _np_ptr(ps), _np_ptr(pr), _np_ptr(pc), P, nq, int(k),
+                               _np_ptr(sc), _np_ptr(ro), _np_ptr(cn), L.RDX_HOST, None))
+    return sc, ro, cn

@@ -1,0 +1,59 @@
+"""Deterministic synthetic corpora/queries of SURVEY.md §8(d) (tests, smoke and bench share them).
+
+numpy path (small sizes, bit-reproducible across hosts): corpus chunk j of 65 536 rows comes from
+default_rng([1234, j]); queries from default_rng(4321); 10 % of the queries are planted near a corpus row
+(q = c_i + 0.3 * eps) and 1 % of the corpus rows are exact duplicates of other rows (tie rule).
+torch path (bench sizes, generated in HBM): same recipe with torch.Generator seeds per chunk.
+Rows are NOT normalised here — the index normalises on ingest, exactly as `collection.add` receives them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+CHUNK = 65536
+
+
+def corpus_chunk(j: int, rows: int, dim: int) -> np.ndarray:
+    return np.random.default_rng([1234, j]).standard_normal((rows, dim), dtype=np.float32)
+
+
+def make_corpus(n: int, dim: int = 1024, duplicates: bool = True) -> np.ndarray:
+    out = np.empty((n, dim), dtype=np.float32)
+    for j, r0 in enumerate(range(0, n, CHUNK)):
+        m = min(CHUNK, n - r0)
+        out[r0:r0 + m] = corpus_chunk(j, m, dim)
+    if duplicates and n >= 200:
+        rng = np.random.default_rng(99)
+        n_dup = n // 100
+        dst = rng.choice(n, size=n_dup, replace=False)
+        src = rng.integers(0, n, size=n_dup)
+        out[dst] = out[src]
+    return out
+
+
+def make_queries(b: int, dim: int = 1024, corpus: np.ndarray | None = None) -> np.ndarray:
+    rng = np.random.default_rng(4321)
+    q = rng.standard_normal((b, dim), dtype=np.float32)
+    if corpus is not None and corpus.shape[0] > 0:
+        n_plant = max(1, b // 10)
+        which = rng.choice(b, size=n_plant, replace=False)
+        rows = rng.integers(0, corpus.shape[0], size=n_plant)
+        eps = rng.standard_normal((n_plant, dim), dtype=np.float32)
+        c = corpus[rows]
+        c = c / np.linalg.norm(c, axis=1, keepdims=True)
+        q[which] = c + 0.3 * eps / np.sqrt(dim)
+    return q
+
+
+def torch_corpus_chunk(j: int, rows: int, dim: int, device):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 * 1000003 + j)
+    return torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32)
+
+
+def torch_queries(b: int, dim: int, device):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(4321)
+    return torch.randn((b, dim), generator=g, device=device, dtype=torch.float32)

@@ -1,0 +1,201 @@
+"""GPU parity: the HIP path (through the C-ABI, rag_dpo_amd/engine.py) against the CPU oracle on the same
+seeded inputs. Bar: row ids bit-exact, scores bit-equal (both sides use the fixed fp64 lane-order sum)."""
+import numpy as np
+import pytest
+
+from rag_dpo_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from rag_dpo_amd import engine
+    return engine
+
+
+def _index(eng, corpus, **opts):
+    ix = eng.HipIndex(corpus.shape[1])
+    ix.add(corpus)
+    for k, v in opts.items():
+        ix.set_option(k, v)
+    return ix
+
+
+def _check(oracle, ix, corpus, q, k, allow=None, expect_path=None):
+    ch = oracle.normalize_rows(corpus)
+    es, er, ec = oracle.cosine_topk(ch, q, k, allow)
+    bits = oracle.pack_mask(allow, corpus.shape[0])
+    gs, gr, gc = ix.search(q, k, bits)
+    st = ix.last_stats()
+    np.testing.assert_array_equal(gc, ec)
+    np.testing.assert_array_equal(gr, er)
+    np.testing.assert_array_equal(gs, es)
+    if expect_path is not None:
+        assert st["path"] == expect_path, st
+    return st
+
+
+def test_normalize_bit_exact(eng, oracle):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((777, 1024)).astype(np.float32)
+    x[3] = 0.0                      # zero vector -> stays zero (reference clamps the norm at 1e-12)
+    x[4] *= 1e-20
+    x[5] *= 1e15
+    x[6, 1:] = 0.0
+    np.testing.assert_array_equal(eng.l2_normalize(x), oracle.normalize_rows(x))
+    ix = _index(eng, x)
+    np.testing.assert_array_equal(ix.get(np.arange(777)), oracle.normalize_rows(x))
+    for d in (64, 384, 768, 4096):
+        y = rng.standard_normal((33, d)).astype(np.float32)
+        np.testing.assert_array_equal(eng.l2_normalize(y), oracle.normalize_rows(y))
+
+
+def test_exact_path_small(eng, oracle):
+    corpus = synth.make_corpus(3000, 1024)
+    q = synth.make_queries(5, 1024, corpus)
+    ix = _index(eng, corpus)
+    st = _check(oracle, ix, corpus, q, 10, expect_path=1)
+    assert st["exact_queries"] == 5
+    _check(oracle, ix, corpus, q[:1], 50, expect_path=1)   # the reference's production shape: B=1, k=50
+
+
+@pytest.mark.parametrize("n,b,k", [(20000, 64, 10), (16919, 4, 50), (30011, 130, 10), (25000, 257, 100)])
+def test_fast_path_parity(eng, oracle, n, b, k):
+    corpus = synth.make_corpus(n, 1024)
+    q = synth.make_queries(b, 1024, corpus)
+    ix = _index(eng, corpus, force_fast=1)
+    st = _check(oracle, ix, corpus, q, k, expect_path=0)
+    assert st["exact_queries"] == 0, st
+    assert st["emitted"] >= b * k
+
+
+def test_fast_path_other_dims(eng, oracle):
+    rng = np.random.default_rng(11)
+    for d in (768, 200, 64):
+        corpus = rng.standard_normal((9000, d)).astype(np.float32)
+        q = rng.standard_normal((70, d)).astype(np.float32)
+        ix = _index(eng, corpus, force_fast=1)
+        _check(oracle, ix, corpus, q, 10, expect_path=0)
+
+
+def test_where_mask(eng, oracle):
+    corpus = synth.make_corpus(20000, 1024)
+    q = synth.make_queries(40, 1024, corpus)
+    rng = np.random.default_rng(3)
+    for frac in (0.5, 0.01, 0.0003):
+        allow = rng.random(20000) < frac
+        for opts in ({"force_fast": 1}, {"force_exact": 1}):
+            ix = _index(eng, corpus, **opts)
+            _check(oracle, ix, corpus, q, 10, allow)
+    none = np.zeros(20000, dtype=bool)
+    ix = _index(eng, corpus, force_fast=1)
+    s, r, c = ix.search(q, 10, oracle.pack_mask(none, 20000))
+    assert (c == 0).all() and (r == -1).all() and np.isneginf(s).all()
+
+
+def test_k_larger_than_corpus_and_tiny(eng, oracle):
+    corpus = synth.make_corpus(7, 1024, duplicates=False)
+    q = synth.make_queries(3, 1024)
+    ix = _index(eng, corpus)
+    s, r, c = ix.search(q, 10)
+    assert (c == 7).all() and (r[:, 7:] == -1).all()
+    _check(oracle, ix, corpus, q, 10)
+    _check(oracle, ix, corpus, q, 1)
+    empty = eng.HipIndex(1024)
+    s, r, c = empty.search(q, 5)
+    assert (c == 0).all() and (r == -1).all()
+
+
+def test_known_answers(eng):
+    d = 1024
+    e0 = np.zeros(d, np.float32); e0[0] = 1
+    e1 = np.zeros(d, np.float32); e1[1] = 1
+    corpus = np.stack([e1, 3 * e0, -e0, e0, e0 + e1])
+    ix = _index(eng, corpus)
+    s, r, c = ix.search(e0[None], 5)
+    assert r[0].tolist() == [1, 3, 4, 0, 2]            # duplicates: lower row id first
+    dist = 1.0 - s[0].astype(np.float64)
+    assert abs(dist[0]) < 1e-6 and abs(dist[1]) < 1e-6  # identical -> 0
+    assert abs(dist[3] - 1) < 1e-6                      # orthogonal -> 1
+    assert abs(dist[4] - 2) < 1e-6                      # antipodal -> 2
+    assert abs(dist[2] - (1 - 2 ** -0.5)) < 1e-6
+
+
+def test_all_rows_identical_ties(eng, oracle):
+    corpus = np.tile(np.random.default_rng(1).standard_normal((1, 1024)).astype(np.float32), (5000, 1))
+    q = synth.make_queries(66, 1024)
+    ix = _index(eng, corpus, force_fast=1)
+    st = _check(oracle, ix, corpus, q, 10)
+    assert st["exact_queries"] == 66        # every query overflows its candidate list -> exact scan
+
+
+def test_candidate_overflow_falls_back(eng, oracle):
+    corpus = synth.make_corpus(20000, 1024)
+    q = synth.make_queries(64, 1024, corpus)
+    ix = _index(eng, corpus, force_fast=1, cand_cap=64, sample_div=1000)
+    st = _check(oracle, ix, corpus, q, 10, expect_path=0)
+    assert st["exact_queries"] > 0
+
+
+def test_update_get_compact(eng, oracle):
+    corpus = synth.make_corpus(6000, 1024)
+    q = synth.make_queries(20, 1024, corpus)
+    ix = _index(eng, corpus[:3000])
+    ix.add(corpus[3000:])
+    assert len(ix) == 6000
+    new = np.random.default_rng(8).standard_normal((3, 1024)).astype(np.float32)
+    ix.update([5, 4000, 5999], new)
+    ref = corpus.copy(); ref[[5, 4000, 5999]] = new
+    for opts in ({"force_fast": 1}, {"force_exact": 1}):
+        for k, v in opts.items():
+            ix.set_option(k, v)
+        _check(oracle, ix, ref, q, 10)
+        ix.set_option("force_fast", 0); ix.set_option("force_exact", 0)
+    keep = np.setdiff1d(np.arange(6000), np.arange(100, 6000, 7))
+    ix.compact(keep)
+    assert len(ix) == keep.size
+    ix.set_option("force_fast", 1)
+    _check(oracle, ix, ref[keep], q, 10)
+    np.testing.assert_array_equal(ix.get([0, 1, keep.size - 1]), oracle.normalize_rows(ref[keep][[0, 1, -1]]))
+
+
+def test_bf16_corpus(eng, oracle):
+    import torch
+    corpus = synth.make_corpus(12000, 1024)
+    cb = torch.from_numpy(corpus).to(torch.bfloat16)
+    ix = eng.HipIndex(1024)
+    ix.add_bf16(cb)
+    ix.set_option("force_fast", 1)
+    q = synth.make_queries(70, 1024, corpus)
+    _check(oracle, ix, cb.to(torch.float32).numpy(), q, 10, expect_path=0)
+
+
+def test_rejects_nan(eng):
+    corpus = synth.make_corpus(100, 1024)
+    bad = corpus.copy(); bad[50, 7] = np.nan
+    ix = eng.HipIndex(1024)
+    with pytest.raises(ValueError):
+        ix.add(bad)
+    assert len(ix) == 0
+    ix.add(corpus)
+    q = synth.make_queries(2, 1024); q[1, 0] = np.inf
+    with pytest.raises(ValueError):
+        ix.search(q, 3)
+    with pytest.raises(ValueError):
+        ix.search(np.zeros((2, 512), np.float32), 3)
+
+
+def test_merge_parity(eng, oracle):
+    rng = np.random.default_rng(2)
+    P, B, k = 8, 50, 10
+    ps = np.sort(rng.standard_normal((P, B, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    ps[3] = ps[2]                                   # equal scores across parts -> tie by row id
+    pr = rng.permutation(P * B * k).reshape(P, B, k).astype(np.int64)
+    pc = rng.integers(0, k + 1, size=(P, B)).astype(np.int32)
+    es, er, ec = oracle.merge_topk(ps, pr, pc, k)
+    gs, gr, gc = eng.merge_topk(ps, pr, pc, k)
+    np.testing.assert_array_equal(gc, ec)
+    for b in range(B):
+        np.testing.assert_array_equal(gr[b, :gc[b]], er[b, :ec[b]])
+        np.testing.assert_array_equal(gs[b, :gc[b]], es[b, :ec[b]])
