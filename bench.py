@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — whole-job queries/s of the cosine top-k hot path on N MI355X (contract: see the task statement).
+
+A "step" is one pass of the hot path over one batch of synthetic queries already resident in HBM:
+librdx search of this rank's corpus shard (K1 normalise -> MFMA scan with fused threshold top-k -> exact
+re-score) + ONE RCCL all-gather of the packed partial top-k + the merge kernel. The corpus total is fixed
+while N grows (strong scaling: BASELINE.json config "10M x 1024 row-sharded over 8 GPUs").
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c4|c3|c2|c5|c1] [--rows R]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line. Extra keys beyond the contract: roofline, cpu_baseline, recall_at_10, path_stats.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from rag_dpo_amd import synth
+from rag_dpo_amd.sharded import HipShard, ShardedSearcher, shard_range
+
+# BASELINE.json configs. c1 = CNIL-sized synthetic corpus, the reference's own shape.
+WORKLOADS = {
+    "c1": dict(rows=16_919, dim=1024, batch=4, k=50, corpus="fp32",
+               desc="CNIL-sized synthetic corpus 16,919 x 1024 fp32, 4 queries (one question's expansions), top-50"),
+    "c2": dict(rows=100_000, dim=1024, batch=64, k=10, corpus="fp32",
+               desc="synthetic 100k x 1024 fp32, batch=64 queries, top-10"),
+    "c3": dict(rows=1_000_000, dim=1024, batch=256, k=100, corpus="fp32",
+               desc="synthetic 1M x 1024 fp32, batch=256 queries, top-100"),
+    "c4": dict(rows=10_000_000, dim=1024, batch=1024, k=10, corpus="fp32",
+               desc="synthetic 10M x 1024 fp32 row-sharded over the GPUs, batch=1024 queries, top-10, all-gather merge"),
+    "c5": dict(rows=10_000_000, dim=1024, batch=1024, k=10, corpus="bf16",
+               desc="synthetic 10M x 1024 bf16 corpus row-sharded over the GPUs, batch=1024 queries, top-10 "
+                    "(query vectors given; BGE-M3 encode not included)"),
+}
+PEAK_HBM_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/f16 MFMA ~2.5 PF
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_shard(shard: HipShard, lo: int, hi: int, dim: int, corpus_kind: str, device):
+    """this rank's rows [lo, hi) of the deterministic synthetic corpus, generated in HBM chunk by chunk"""
+    shard.index.reserve(hi - lo)
+    j0, j1 = lo // synth.CHUNK, (hi + synth.CHUNK - 1) // synth.CHUNK
+    for j in range(j0, j1):
+        r0 = j * synth.CHUNK
+        rows = synth.torch_corpus_chunk(j, synth.CHUNK, dim, device)
+        a, b = max(lo, r0) - r0, min(hi, r0 + synth.CHUNK) - r0
+        rows = rows[a:b].contiguous()
+        if corpus_kind == "bf16":
+            shard.index.add_bf16(rows.to(torch.bfloat16))
+        else:
+            shard.index.add(rows)
+        del rows
+    torch.cuda.synchronize(device)
+
+
+def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, total_rows: int):
+    """rank 0, N=1 only. The oracle is the CHECKER and the timed CPU baseline; never the thing shipped."""
+    from oracle import oracle as O
+    O.build()
+    dim, k, B = wl["dim"], wl["k"], wl["batch"]
+    n = len(shard)
+    sample = min(n, 262_144)
+    rows_hat = shard.index.get(np.arange(sample, dtype=np.int64))        # stored (normalised) rows -> host
+    q = queries.cpu().numpy()
+    qhat = O.normalize_rows(q)
+    # --- CPU baseline: fp32 BLAS sgemm + partial sort on all host cores, bounded sample, scaled to the full corpus
+    threads = os.cpu_count() or 1
+    bq = min(B, 1024)
+    t_best, reps = None, 0
+    t_end = time.time() + 12.0
+    while reps < 3 or (time.time() < t_end and reps < 20):
+        t0 = time.time()
+        O.topk_blas_f32(rows_hat, qhat[:bq], min(k, sample))
+        dt = time.time() - t0
+        t_best = dt if t_best is None else min(t_best, dt)
+        reps += 1
+    qps_sample = bq / t_best
+    cpu = {
+        "value": round(qps_sample * sample / total_rows, 2), "unit": "queries/s", "cores": threads, "kind": "port",
+        "sample": f"oracle.topk_blas_f32 (numpy fp32 sgemm + argpartition, {threads} threads) on the first {sample} "
+                  f"normalised rows x {bq} queries, best of {reps} ({t_best*1e3:.0f} ms); value = sample QPS x {sample}/{total_rows} rows",
+    }
+    # --- recall@k vs the exact C oracle on the same bounded sample (GPU restricted to it by the row bitmap)
+    nchk = min(B, 16)
+    es, er, ec = O.cosine_topk(rows_hat, q[:nchk], k)
+    allow = np.zeros(n, dtype=bool)
+    allow[:sample] = True
+    gs, gr, gc = shard.index.search(q[:nchk], k, O.pack_mask(allow, n))
+    hits = sum(len(set(er[b, :ec[b]].tolist()) & set(gr[b, :gc[b]].tolist())) for b in range(nchk))
+    recall = hits / max(1, int(ec.sum()))
+    exact_ids = bool((gr == er).all() and (gc == ec).all())
+    max_ds = float(np.abs(gs[:, :k].astype(np.float64) - es.astype(np.float64)).max()) if k else 0.0
+    # --- full-size property: every id the full search returned, re-scored by the oracle, must equal the GPU score
+    fs, fr, fc = shard.index.search(q[:nchk], k)
+    ok_full = True
+    for b in range(nchk):
+        rr = fr[b, :fc[b]]
+        ref = O.scores(shard.index.get(rr), qhat[b])
+        ok_full &= bool((ref == fs[b, :fc[b]]).all()) and bool((np.diff(fs[b, :fc[b]].astype(np.float64)) <= 0).all())
+    rec = {"value": round(recall, 6), "k": k, "queries": nchk, "sample_rows": sample, "ids_bit_exact": exact_ids,
+           "max_abs_score_diff": max_ds, "full_corpus_returned_scores_match_oracle": ok_full}
+    return cpu, rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="override the workload's total corpus rows")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.rows:
+        wl["rows"] = args.rows
+    if args.batch:
+        wl["batch"] = args.batch
+    if args.k:
+        wl["k"] = args.k
+    rows, dim, B, k = wl["rows"], wl["dim"], wl["batch"], wl["k"]
+    lo, hi = shard_range(rows, world, rank)
+
+    t_build = time.time()
+    shard = HipShard(dim, local_rank, row_offset=lo)
+    build_shard(shard, lo, hi, dim, wl["corpus"], device)
+    log(f"[rank {rank}] shard rows [{lo}, {hi}) resident in {time.time() - t_build:.1f}s")
+    searcher = ShardedSearcher(shard)
+    queries = synth.torch_queries(B, dim, device)
+    shard.index.set_option("profile", 1)    # HIP events around every kernel, on the stream they run on
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        searcher.search(queries, k)
+    barrier()
+    scan_ms, tot_ms, stats = 0.0, 0.0, None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        searcher.search(queries, k)
+        st = shard.index.last_stats()   # host struct copy, no device work
+        scan_ms += st["ms_scan_main"]
+        tot_ms += st["ms_total"]
+        stats = st
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out = None
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        qps = B * args.steps / elapsed
+        n_local = hi - lo
+        dim_pad = (dim + 63) // 64 * 64
+        launch_ms = scan_ms / args.steps
+        flops = 2.0 * B * n_local * dim_pad          # algorithmic flop of one main-scan launch
+        bytes_ = n_local * dim_pad * 2.0 + B * dim_pad * 2.0   # fp16 scan copy read once + queries
+        t_hbm, t_mfma = bytes_ / (PEAK_HBM_GBS * 1e9), flops / (PEAK_MFMA_TFLOPS * 1e12)
+        roof = None
+        if stats and stats["path"] == 0 and launch_ms > 0:
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(f"{args.workload}_n{world}")
+                except Exception:
+                    traffic = None
+            if t_mfma >= t_hbm:
+                ach = flops / (launch_ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic}
+            else:
+                ach = bytes_ / (launch_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic}
+            roof.update({"kernel": "rdx::k_scan<BN,EPI_EMIT> (main scan)", "avg_launch_ms": round(launch_ms, 4),
+                         "launch_rows": n_local, "launch_queries": B,
+                         "hbm_frac_of_8TBs": round(bytes_ / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                         "mfma_frac_of_2.5PF": round(flops / (launch_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)})
+        cpu, rec = None, None
+        if world == 1 and not args.no_cpu:
+            try:
+                cpu, rec = cpu_baseline_and_recall(shard, queries, wl, rows)
+            except Exception as e:   # the checker must never take the measured number down with it
+                log(f"cpu_baseline/recall leg failed: {e!r}")
+        out = {
+            "metric": "queries/sec, d=1024 cosine top-k (exact, ids == CPU oracle)", "value": round(qps, 1), "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16 MFMA scan + f64 exact re-score",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "rows_total": rows, "rows_per_gpu": n_local, "dim": dim,
+                       "batch": B, "k": k, "corpus_dtype": wl["corpus"], "parallelism": f"row-shard x{world} + all-gather merge"},
+            "roofline": roof, "cpu_baseline": cpu, "recall_at_10": rec,
+            "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4), "exact_fallback_queries": stats["exact_queries"],
+                           "emitted_per_query": round(stats["emitted"] / max(1, B), 1),
+                           "rescored_per_query": round(stats["rescored"] / max(1, B), 2), "sample_rows": stats["sample_rows"],
+                           "ms": {n_: round(stats[n_], 4) for n_ in ("ms_normalize", "ms_scan_sample", "ms_tau", "ms_scan_main",
+                                                                     "ms_refine", "ms_exact")}},
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

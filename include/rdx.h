@@ -77,7 +77,8 @@ int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep);
 
 /* Options (tests and benchmarks): "force_exact" 0/1, "force_fast" 0/1 (MFMA scan even for small
  * problems), "sample_div" >=1, "cand_cap" 0 (auto) or >=64,
- * "profile" 0/1 (record HIP events around every kernel of the next searches). */
+ * "profile" 0/1 (record HIP events around every kernel of the next searches); "row_base" >= 0:
+ * added to every returned row id, so a shard holding rows [base, base+count) answers with GLOBAL ids. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);
 
 /* `SentenceTransformer.encode(..., normalize_embeddings=True)`'s last step
@@ -101,6 +102,12 @@ int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k, const uint
 int rdx_merge_topk(int device, const float* part_score, const int64_t* part_row,
                    const int32_t* part_count, int n_parts, int64_t nq, int k, float* out_score,
                    int64_t* out_row, int32_t* out_count, int space, void* stream);
+
+/* Same merge, reading the partials straight out of the all-gather receive buffer (device memory):
+ * part p starts part_stride bytes (multiple of 16) after part p-1 and is one rank's packed contribution
+ * rows int64[nq][k] | scores f32[nq][k] | counts int32[nq]. Outputs are device pointers; k >= 1. */
+int rdx_merge_topk_packed(int device, const void* packed, int64_t part_stride, int n_parts, int64_t nq,
+                          int k, float* out_score, int64_t* out_row, int32_t* out_count, void* stream);
 
 /* Diagnostics of the last rdx_search on this index (valid after the stream has synchronised). */
 typedef struct rdx_search_stats {

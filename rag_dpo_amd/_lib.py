@@ -61,6 +61,7 @@ SYMBOLS = {
     "rdx_l2_normalize": (_i, [_i, _vp, _i64, _i, _vp, _i, _vp]),
     "rdx_search": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "rdx_merge_topk": (_i, [_i, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _vp]),
+    "rdx_merge_topk_packed": (_i, [_i, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "rdx_search_last_stats": (_i, [_vp, ctypes.POINTER(SearchStats)]),
 }
 

@@ -1,0 +1,478 @@
+"""Chroma-shaped `Collection` / `PersistentClient` whose vectors live in MI355X HBM (librdx).
+
+Mirrors exactly the part of chromadb's API that RAG-DPO calls:
+    collection.query(query_embeddings=, n_results=, where=, include=)   src/rag/retriever.py:215-220, 380-385
+    collection.add(ids=, documents=, embeddings=, metadatas=)           src/processing/create_chromadb_index.py:374-379
+    collection.get(limit=, offset=, where=, ids=, include=)             src/rag/bm25_index.py:211-215 and others
+    collection.count() / delete(ids=) / update(ids=, metadatas=)        ingest_enterprise.py:272, tag_all_chunks.py:215
+    client.get_collection / create_collection / delete_collection       app.py:58-59, create_chromadb_index.py:93-130
+Everything that crosses this boundary is plain Python lists/dicts/strs/floats, as with chromadb.
+ids/documents/metadata stay on the host; embeddings go to the device index (`engine`). The engine is
+always librdx (rag_dpo_amd.engine.HipIndex): there is no CPU search path in this package.
+
+Distances keep Chroma's cosine convention: distance = 1 - cos, ascending (so that
+`similarity_score = 1/(1+distance)` reference retriever.py:39-42 and the 0.80 relevance threshold
+reference validators.py:64-81 keep their meaning). The search itself is exact (brute force), not HNSW.
+"""
+from __future__ import annotations
+
+import json
+import os
+import threading
+from typing import Any, Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import where as W
+
+DEFAULT_INCLUDE_QUERY = ["metadatas", "documents", "distances"]
+DEFAULT_INCLUDE_GET = ["metadatas", "documents"]
+_VALID_INCLUDE = {"embeddings", "documents", "metadatas", "distances", "uris", "data"}
+
+
+class DuplicateIDError(ValueError):
+    pass
+
+
+class NotFoundError(ValueError):
+    pass
+
+
+def _default_engine_factory(dim: int, device: int):
+    from .engine import HipIndex   # raises RdxUnavailable when librdx / a gfx950 GPU is missing
+    return HipIndex(dim, device)
+
+
+def _as_matrix(embeddings, what: str) -> np.ndarray:
+    a = np.asarray(embeddings, dtype=np.float32)
+    if a.ndim == 1 and a.size > 0:
+        a = a[None, :]
+    if a.ndim != 2 or a.shape[0] == 0 or a.shape[1] == 0:
+        raise ValueError(f"Expected {what} to be a non-empty list of embeddings, got shape {a.shape}")
+    return np.ascontiguousarray(a)
+
+
+class Collection:
+    def __init__(self, name: str, metadata: Optional[dict] = None, device: int = 0,
+                 engine_factory: Optional[Callable[[int, int], Any]] = None, _client=None):
+        self.name = name
+        self.metadata = dict(metadata or {})
+        space = self.metadata.get("hnsw:space", "cosine")
+        if space != "cosine":
+            raise ValueError(f"only the cosine space is implemented (the reference uses 'hnsw:space': 'cosine'), got {space!r}")
+        self._device = device
+        self._factory = engine_factory or _default_engine_factory
+        self._engine = None
+        self._dim: Optional[int] = None
+        self._ids: List[str] = []              # row -> id ("" when tombstoned)
+        self._docs: List[Optional[str]] = []
+        self._row_of: Dict[str, int] = {}
+        self._alive = np.zeros(0, dtype=bool)
+        self._n_dead = 0
+        self._cols: Dict[str, W.Column] = {}
+        self._lock = threading.RLock()
+        self._client = _client
+
+    # ---- small helpers ----------------------------------------------------------------------
+    @property
+    def _rows(self) -> int:
+        return len(self._ids)
+
+    def _ensure_engine(self, dim: int):
+        if self._engine is None:
+            self._engine = self._factory(dim, self._device)
+            self._dim = dim
+        elif dim != self._dim:
+            raise ValueError(f"Embedding dimension {dim} does not match collection dimensionality {self._dim}")
+
+    def _set_meta(self, row: int, meta: Optional[dict], replace: bool):
+        if replace:
+            for col in self._cols.values():
+                col.kind[row] = W.K_MISSING
+        if not meta:
+            return
+        for k, v in meta.items():
+            if not isinstance(k, str):
+                raise ValueError(f"Expected metadata key to be a str, got {k!r}")
+            col = self._cols.get(k)
+            if col is None:
+                col = self._cols[k] = W.Column(self._rows)
+            col.set(row, v)
+
+    def _meta_of(self, row: int) -> Optional[dict]:
+        out = {}
+        for k, col in self._cols.items():
+            v = col.get(row)
+            if v is not None:
+                out[k] = v
+        return out or None
+
+    def _grow_cols(self, n: int):
+        for col in self._cols.values():
+            col.resize(n)
+        if self._alive.shape[0] < n:
+            a = np.zeros(max(n, self._alive.shape[0] * 3 // 2 + 16), dtype=bool)
+            a[: self._alive.shape[0]] = self._alive
+            self._alive = a
+
+    def _mask(self, where: Optional[dict]) -> Optional[np.ndarray]:
+        """row bitmap source: `where` pre-filter AND not-deleted; None = everything passes"""
+        n = self._rows
+        m = W.evaluate(where, self._cols, n)
+        if self._n_dead:
+            m = self._alive[:n].copy() if m is None else (m & self._alive[:n])
+        return m
+
+    @staticmethod
+    def _check_include(include: Sequence[str], allowed: set):
+        for inc in include:
+            if inc not in _VALID_INCLUDE or inc not in allowed:
+                raise ValueError(f"Expected include item to be one of {sorted(allowed)}, got {inc}")
+
+    def _maybe_compact(self):
+        if self._n_dead > max(1024, self._rows // 5):
+            self._compact()
+
+    def _compact(self):
+        n = self._rows
+        keep = np.flatnonzero(self._alive[:n])
+        self._engine.compact(keep)
+        self._ids = [self._ids[i] for i in keep]
+        self._docs = [self._docs[i] for i in keep]
+        self._cols = {k: c.take(keep) for k, c in self._cols.items()}
+        self._alive = np.ones(len(keep), dtype=bool)
+        self._row_of = {s: i for i, s in enumerate(self._ids)}
+        self._n_dead = 0
+
+    # ---- chromadb.Collection API ---------------------------------------------------------------
+    def count(self) -> int:
+        with self._lock:
+            return self._rows - self._n_dead
+
+    def add(self, ids, embeddings=None, metadatas=None, documents=None, **_ignored):
+        """reference create_chromadb_index.py:374-379, ingest_enterprise.py:241-246. Existing ids are skipped
+        (chromadb's add never overwrites); duplicate ids inside one call raise DuplicateIDError."""
+        if isinstance(ids, str):
+            ids = [ids]
+        ids = list(ids)
+        if not ids:
+            raise ValueError("Expected IDs to be a non-empty list, got 0 IDs")
+        if embeddings is None:
+            raise ValueError("this collection has no embedding function: pass embeddings= "
+                             "(the reference always does, create_chromadb_index.py:374-379)")
+        emb = _as_matrix(embeddings, "embeddings")
+        n = len(ids)
+        if emb.shape[0] != n:
+            raise ValueError(f"Unequal lengths for fields: ids: {n}, embeddings: {emb.shape[0]}")
+        for name, lst in (("metadatas", metadatas), ("documents", documents)):
+            if lst is not None and len(lst) != n:
+                raise ValueError(f"Unequal lengths for fields: ids: {n}, {name}: {len(lst)}")
+        if len(set(ids)) != n:
+            seen, dups = set(), set()
+            for s in ids:
+                (dups if s in seen else seen).add(s)
+            raise DuplicateIDError(f"Expected IDs to be unique, found duplicates of: {', '.join(sorted(dups))}")
+        for s in ids:
+            if not isinstance(s, str) or not s:
+                raise ValueError(f"Expected ID to be a non-empty str, got {s!r}")
+        with self._lock:
+            self._ensure_engine(emb.shape[1])
+            fresh = [i for i, s in enumerate(ids) if s not in self._row_of]
+            if not fresh:
+                return
+            if metadatas is not None:   # validate before anything is stored
+                for i in fresh:
+                    for v in (metadatas[i] or {}).values():
+                        W.kind_of(v)
+            sel = emb if len(fresh) == n else np.ascontiguousarray(emb[fresh])
+            row0 = self._rows
+            self._engine.add(sel)   # raises ValueError on NaN/Inf: nothing stored
+            self._grow_cols(row0 + len(fresh))
+            for j, i in enumerate(fresh):
+                row = row0 + j
+                self._ids.append(ids[i])
+                self._docs.append(documents[i] if documents is not None else None)
+                self._row_of[ids[i]] = row
+                self._alive[row] = True
+                self._set_meta(row, metadatas[i] if metadatas is not None else None, replace=False)
+
+    def update(self, ids, embeddings=None, metadatas=None, documents=None, **_ignored):
+        """reference tag_all_chunks.py:215,224 (metadatas only). Metadata updates MERGE into the stored dict,
+        as chromadb does; ids that do not exist are ignored."""
+        if isinstance(ids, str):
+            ids = [ids]
+        ids = list(ids)
+        n = len(ids)
+        emb = _as_matrix(embeddings, "embeddings") if embeddings is not None else None
+        for name, lst in (("embeddings", emb), ("metadatas", metadatas), ("documents", documents)):
+            if lst is not None and len(lst) != n:
+                raise ValueError(f"Unequal lengths for fields: ids: {n}, {name}: {len(lst)}")
+        with self._lock:
+            hit = [(i, self._row_of[s]) for i, s in enumerate(ids) if s in self._row_of]
+            if emb is not None and hit:
+                self._ensure_engine(emb.shape[1])
+                self._engine.update(np.array([r for _, r in hit], dtype=np.int64),
+                                    np.ascontiguousarray(emb[[i for i, _ in hit]]))
+            for i, row in hit:
+                if metadatas is not None and metadatas[i]:
+                    self._set_meta(row, metadatas[i], replace=False)
+                if documents is not None:
+                    self._docs[row] = documents[i]
+
+    def upsert(self, ids, embeddings=None, metadatas=None, documents=None, **_ignored):
+        if isinstance(ids, str):
+            ids = [ids]
+        ids = list(ids)
+        with self._lock:
+            old = [i for i, s in enumerate(ids) if s in self._row_of]
+            new = [i for i, s in enumerate(ids) if s not in self._row_of]
+            pick = lambda lst, idx: None if lst is None else [lst[i] for i in idx]
+            emb = _as_matrix(embeddings, "embeddings") if embeddings is not None else None
+            if old:
+                self.update([ids[i] for i in old], None if emb is None else emb[old], pick(metadatas, old), pick(documents, old))
+            if new:
+                self.add([ids[i] for i in new], None if emb is None else emb[new], pick(metadatas, new), pick(documents, new))
+
+    def delete(self, ids=None, where=None, **_ignored):
+        """reference ingest_enterprise.py:272,304 (ids in batches of 5000). Rows are tombstoned (excluded from
+        every search through the row bitmap) and compacted out of HBM once a fifth of the rows is dead."""
+        with self._lock:
+            rows: List[int] = []
+            if ids is not None:
+                if isinstance(ids, str):
+                    ids = [ids]
+                rows = [self._row_of[s] for s in ids if s in self._row_of]
+                if where is not None and rows:
+                    m = W.evaluate(where, self._cols, self._rows)
+                    rows = [r for r in rows if m is None or m[r]]
+            elif where is not None:
+                m = self._mask(where)
+                rows = np.flatnonzero(m).tolist() if m is not None else list(range(self._rows))
+            else:
+                raise ValueError("delete needs ids= or where=")
+            for r in rows:
+                if self._alive[r]:
+                    self._alive[r] = False
+                    self._n_dead += 1
+                    del self._row_of[self._ids[r]]
+                    self._ids[r] = ""
+                    self._docs[r] = None
+            if rows:
+                self._maybe_compact()
+
+    def get(self, ids=None, where=None, limit=None, offset=None, where_document=None, include=None, **_ignored):
+        """reference bm25_index.py:211-215 (paging with limit/offset), create_chromadb_index.py:118,452-468,
+        ingest_enterprise.py:142-145. Order = insertion order, like chromadb."""
+        include = DEFAULT_INCLUDE_GET if include is None else list(include)
+        self._check_include(include, {"embeddings", "documents", "metadatas", "uris", "data"})
+        if where_document is not None:
+            raise ValueError("where_document is not implemented (the reference never passes it)")
+        with self._lock:
+            if ids is not None:
+                if isinstance(ids, str):
+                    ids = [ids]
+                rows = sorted(self._row_of[s] for s in set(ids) if s in self._row_of)
+                if where is not None and rows:
+                    m = W.evaluate(where, self._cols, self._rows)
+                    rows = [r for r in rows if m is None or m[r]]
+            else:
+                m = self._mask(where)
+                rows = list(range(self._rows)) if m is None else np.flatnonzero(m).tolist()
+            off = int(offset or 0)
+            rows = rows[off: off + int(limit)] if limit is not None else rows[off:]
+            out = {
+                "ids": [self._ids[r] for r in rows],
+                "embeddings": None,
+                "documents": [self._docs[r] for r in rows] if "documents" in include else None,
+                "metadatas": [self._meta_of(r) for r in rows] if "metadatas" in include else None,
+                "uris": None,
+                "data": None,
+                "included": include,
+            }
+            if "embeddings" in include:
+                out["embeddings"] = (self._engine.get(np.array(rows, dtype=np.int64)) if rows and self._engine is not None
+                                     else np.zeros((0, self._dim or 0), dtype=np.float32))
+            return out
+
+    def peek(self, limit: int = 10):
+        return self.get(limit=limit, include=["embeddings", "metadatas", "documents"])
+
+    def query(self, query_embeddings=None, n_results: int = 10, where=None, where_document=None, include=None,
+              query_texts=None, **_ignored):
+        """reference src/rag/retriever.py:215-220, 380-385 (one query, n_results=50, optional where, include
+        documents+metadatas+distances) and create_chromadb_index.py:405-408 (no include/where)."""
+        include = DEFAULT_INCLUDE_QUERY if include is None else list(include)
+        self._check_include(include, _VALID_INCLUDE)
+        if query_embeddings is None:
+            raise ValueError("this collection has no embedding function: pass query_embeddings= "
+                             "(the reference always does, retriever.py:215-220)")
+        if where_document is not None:
+            raise ValueError("where_document is not implemented (the reference never passes it)")
+        if not isinstance(n_results, (int, np.integer)) or isinstance(n_results, bool) or n_results <= 0:
+            raise ValueError(f"Number of requested results {n_results}, cannot be negative, or zero.")
+        q = _as_matrix(query_embeddings, "query_embeddings")
+        nq = q.shape[0]
+        with self._lock:
+            if self._engine is None:   # nothing was ever added
+                empty = [[] for _ in range(nq)]
+                return {"ids": [[] for _ in range(nq)], "embeddings": None,
+                        "documents": [list(e) for e in empty] if "documents" in include else None,
+                        "metadatas": [list(e) for e in empty] if "metadatas" in include else None,
+                        "distances": [list(e) for e in empty] if "distances" in include else None,
+                        "uris": None, "data": None, "included": include}
+            if q.shape[1] != self._dim:
+                raise ValueError(f"Embedding dimension {q.shape[1]} does not match collection dimensionality {self._dim}")
+            m = self._mask(where)
+            bits = W.pack_bits(m) if m is not None else None
+            scores, rows, counts = self._engine.search(q, int(n_results), bits)
+            dist = (np.float32(1.0) - scores).astype(np.float32)   # Chroma cosine distance, fp32 like chromadb
+            out_ids, out_docs, out_meta, out_dist, out_emb = [], [], [], [], []
+            for b in range(nq):
+                rr = rows[b, : counts[b]].tolist()
+                out_ids.append([self._ids[r] for r in rr])
+                if "documents" in include:
+                    out_docs.append([self._docs[r] for r in rr])
+                if "metadatas" in include:
+                    out_meta.append([self._meta_of(r) for r in rr])
+                if "distances" in include:
+                    out_dist.append([float(x) for x in dist[b, : counts[b]]])
+                if "embeddings" in include:
+                    out_emb.append(self._engine.get(np.array(rr, dtype=np.int64)) if rr
+                                   else np.zeros((0, self._dim), dtype=np.float32))
+            return {
+                "ids": out_ids,
+                "embeddings": out_emb if "embeddings" in include else None,
+                "documents": out_docs if "documents" in include else None,
+                "metadatas": out_meta if "metadatas" in include else None,
+                "distances": out_dist if "distances" in include else None,
+                "uris": None,
+                "data": None,
+                "included": include,
+            }
+
+    def modify(self, name: Optional[str] = None, metadata: Optional[dict] = None):
+        with self._lock:
+            if name is not None:
+                if self._client is not None:
+                    self._client._rename(self.name, name)
+                self.name = name
+            if metadata is not None:
+                self.metadata = dict(metadata)
+
+    # ---- persistence: own shard format ------------------------------------------
+    def _save(self, path: str):
+        with self._lock:
+            if self._n_dead:
+                self._compact()
+            os.makedirs(path, exist_ok=True)
+            n = self._rows
+            meta = {"name": self.name, "metadata": self.metadata, "dim": self._dim, "rows": n, "format": 1}
+            if n:
+                emb = self._engine.get(np.arange(n, dtype=np.int64))   # normalised fp32 rows
+                np.save(os.path.join(path, "embeddings.f32.npy"), emb)
+            with open(os.path.join(path, "records.jsonl"), "w", encoding="utf-8") as f:
+                for r in range(n):
+                    f.write(json.dumps({"id": self._ids[r], "document": self._docs[r], "metadata": self._meta_of(r)},
+                                       ensure_ascii=False) + "\n")
+            with open(os.path.join(path, "collection.json"), "w", encoding="utf-8") as f:
+                json.dump(meta, f)
+
+    def _load(self, path: str):
+        with open(os.path.join(path, "collection.json"), encoding="utf-8") as f:
+            meta = json.load(f)
+        self.metadata = meta.get("metadata") or {}
+        n = int(meta.get("rows", 0))
+        if not n:
+            return
+        emb = np.load(os.path.join(path, "embeddings.f32.npy"), mmap_mode="r", allow_pickle=False)
+        ids, docs, metas = [], [], []
+        with open(os.path.join(path, "records.jsonl"), encoding="utf-8") as f:
+            for line in f:
+                rec = json.loads(line)
+                ids.append(rec["id"])
+                docs.append(rec.get("document"))
+                metas.append(rec.get("metadata"))
+        step = 65536
+        for a in range(0, n, step):
+            b = min(n, a + step)
+            self.add(ids=ids[a:b], embeddings=np.asarray(emb[a:b]), documents=docs[a:b], metadatas=metas[a:b])
+
+
+class PersistentClient:
+    """chromadb.PersistentClient look-alike (reference app.py:58-59, create_chromadb_index.py:70-130,
+    eval/run_eval.py:712-715): `PersistentClient(path).get_collection("rag_dpo_chunks")`.
+    Collections are loaded into HBM on open and written back by persist()/close()."""
+
+    def __init__(self, path: Optional[str] = None, device: int = 0, engine_factory=None, settings=None, **_ignored):
+        self.path = path
+        self._device = device
+        self._factory = engine_factory
+        self._cols: Dict[str, Collection] = {}
+        if path and os.path.isdir(path):
+            for name in sorted(os.listdir(path)):
+                d = os.path.join(path, name)
+                if os.path.exists(os.path.join(d, "collection.json")):
+                    c = Collection(name, device=device, engine_factory=engine_factory, _client=self)
+                    c._load(d)
+                    self._cols[name] = c
+
+    def create_collection(self, name: str, metadata: Optional[dict] = None, get_or_create: bool = False, **_ignored):
+        if name in self._cols:
+            if get_or_create:
+                return self._cols[name]
+            raise ValueError(f"Collection {name} already exists")
+        c = Collection(name, metadata=metadata, device=self._device, engine_factory=self._factory, _client=self)
+        self._cols[name] = c
+        return c
+
+    def get_collection(self, name: str, **_ignored) -> Collection:
+        if name not in self._cols:
+            raise NotFoundError(f"Collection {name} does not exist.")
+        return self._cols[name]
+
+    def get_or_create_collection(self, name: str, metadata: Optional[dict] = None, **_ignored) -> Collection:
+        return self.create_collection(name, metadata=metadata, get_or_create=True)
+
+    def delete_collection(self, name: str):
+        if name not in self._cols:
+            raise NotFoundError(f"Collection {name} does not exist.")
+        c = self._cols.pop(name)
+        if c._engine is not None and hasattr(c._engine, "close"):
+            c._engine.close()
+        if self.path:
+            d = os.path.join(self.path, name)
+            if os.path.isdir(d):
+                for fn in ("collection.json", "records.jsonl", "embeddings.f32.npy"):
+                    fp = os.path.join(d, fn)
+                    if os.path.exists(fp):
+                        os.remove(fp)
+                try:
+                    os.rmdir(d)
+                except OSError:
+                    pass
+
+    def list_collections(self):
+        return list(self._cols.values())
+
+    def _rename(self, old: str, new: str):
+        if new in self._cols:
+            raise ValueError(f"Collection {new} already exists")
+        self._cols[new] = self._cols.pop(old)
+
+    def persist(self):
+        if not self.path:
+            return
+        os.makedirs(self.path, exist_ok=True)
+        for name, c in self._cols.items():
+            c._save(os.path.join(self.path, name))
+
+    def close(self):
+        self.persist()
+
+    def heartbeat(self) -> int:
+        import time
+        return int(time.time() * 1e9)
+
+
+def Client(**kw):   # chromadb.Client(): in-memory
+    return PersistentClient(path=None, **kw)

@@ -81,8 +81,11 @@ __global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, 
 
 // C1. merge n_parts partial top-k lists per query. One block per query; n_parts*k <= MERGE_MAX.
 constexpr int MERGE_MAX = 4096;
+// part p of each array starts stride_* ELEMENTS after part p-1 (contiguous [n_parts][nq][k] arrays, or the
+// packed all-gather receive buffer).
 __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ part_score, const int64_t* __restrict__ part_row,
-                                               const int32_t* __restrict__ part_count, int n_parts, int64_t nq, int k,
+                                               const int32_t* __restrict__ part_count, int64_t stride_s, int64_t stride_r,
+                                               int64_t stride_c, int n_parts, int64_t nq, int k,
                                                float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                int32_t* __restrict__ out_count) {
     __shared__ float s_s[MERGE_MAX];
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ part_sc
         int acc = 0;
         for (int p = 0; p < n_parts; ++p) {
             base[p] = acc;
-            int c = part_count[(int64_t)p * nq + q];
+            int c = part_count[(int64_t)p * stride_c + q];
             acc += c < 0 ? 0 : (c > k ? k : c);
         }
         base[n_parts] = acc;
@@ -102,8 +105,8 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ part_sc
     for (int p = 0; p < n_parts; ++p) {
         const int c = base[p + 1] - base[p];
         for (int i = threadIdx.x; i < c; i += blockDim.x) {
-            s_s[base[p] + i] = part_score[((int64_t)p * nq + q) * k + i];
-            s_r[base[p] + i] = part_row[((int64_t)p * nq + q) * k + i];
+            s_s[base[p] + i] = part_score[(int64_t)p * stride_s + q * k + i];
+            s_r[base[p] + i] = part_row[(int64_t)p * stride_r + q * k + i];
         }
     }
     __syncthreads();

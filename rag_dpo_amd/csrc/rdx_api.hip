@@ -91,6 +91,7 @@ struct rdx_index {
     int force_exact = 0, force_fast = 0, profile = 0;
     int sample_div = 32;
     int64_t cand_cap = 0;   // 0 = automatic
+    int64_t row_base = 0;   // added to every returned row id (global ids of a shard)
 
     // scratch (grow-only; never allocated inside a warmed-up search)
     DevBuf staging, qraw, qhat, qshadow, tau, cnt, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
@@ -236,6 +237,9 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "sample_div") {
         if (value < 1) return fail(RDX_ERR_INVALID, "sample_div must be >= 1");
         h->sample_div = (int)std::min<int64_t>(value, 1 << 20);
+    } else if (n == "row_base") {
+        if (value < 0) return fail(RDX_ERR_INVALID, "row_base must be >= 0");
+        h->row_base = value;
     } else if (n == "cand_cap") {
         if (value != 0 && value < 64) return fail(RDX_ERR_INVALID, "cand_cap must be 0 (auto) or >= 64");
         h->cand_cap = value;
@@ -473,7 +477,7 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
                                h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>());
             HIP_TRY(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_select_dense, dim3(nq), dim3(1024), 0, st, h->dense.as<float>(), h->rows, d_list + j0, k, (int64_t)0,
+        hipLaunchKernelGGL(k_select_dense, dim3(nq), dim3(1024), 0, st, h->dense.as<float>(), h->rows, d_list + j0, k, h->row_base,
                            d_score, d_row, d_count);
         HIP_TRY(hipGetLastError());
     }
@@ -568,7 +572,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, p, grid, st));
         mark(4);
         hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(256), 0, st, h->cand.as<uint2>(), h->cnt.as<uint32_t>(), cap, k, h->two_e(),
-                           h->qhat.as<float>(), h->master, h->dim, (int64_t)0, d_score, d_row, d_count,
+                           h->qhat.as<float>(), h->master, h->dim, h->row_base, d_score, d_row, d_count,
                            h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
         HIP_TRY(hipGetLastError());
         mark(5);
@@ -715,7 +719,8 @@ extern "C" int rdx_merge_topk(int device, const float* part_score, const int64_t
         d_or = orow.as<int64_t>();
         d_oc = oc.as<int32_t>();
     }
-    hipLaunchKernelGGL(k_merge, dim3((int)nq), dim3(256), 0, st, d_ps, d_pr, d_pc, n_parts, nq, k, d_os, d_or, d_oc);
+    hipLaunchKernelGGL(k_merge, dim3((int)nq), dim3(256), 0, st, d_ps, d_pr, d_pc, (int64_t)nq * k, (int64_t)nq * k, (int64_t)nq, n_parts, nq, k,
+                       d_os, d_or, d_oc);
     HIP_TRY(hipGetLastError());
     if (space == RDX_HOST) {
         if (k > 0) {
@@ -726,5 +731,23 @@ extern "C" int rdx_merge_topk(int device, const float* part_score, const int64_t
         HIP_TRY(hipStreamSynchronize(st));
         for (DevBuf* b : {&ps, &pr, &pc, &os, &orow, &oc}) b->release();
     }
+    return RDX_OK;
+}
+
+// the packed layout one rank contributes to the all-gather: rows i64[nq][k] | scores f32[nq][k] | counts i32[nq]
+extern "C" int rdx_merge_topk_packed(int device, const void* packed, int64_t part_stride, int n_parts, int64_t nq, int k,
+                                     float* out_score, int64_t* out_row, int32_t* out_count, void* stream) {
+    if (n_parts < 1 || n_parts > 64 || nq < 0 || k < 1) return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: bad shape");
+    if ((int64_t)n_parts * k > MERGE_MAX) return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: n_parts * k exceeds " + std::to_string(MERGE_MAX));
+    if (part_stride % 16 != 0 || part_stride < nq * k * 12 + nq * 4)
+        return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: part_stride must be a multiple of 16 covering one packed partial");
+    if (nq == 0) return RDX_OK;
+    if (!packed || !out_score || !out_row || !out_count) return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: null pointer");
+    HIP_TRY(hipSetDevice(device));
+    const char* b = reinterpret_cast<const char*>(packed);
+    hipLaunchKernelGGL(k_merge, dim3((int)nq), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(b + nq * k * 8),
+                       reinterpret_cast<const int64_t*>(b), reinterpret_cast<const int32_t*>(b + nq * k * 12), part_stride / 4,
+                       part_stride / 8, part_stride / 4, n_parts, nq, k, out_score, out_row, out_count);
+    HIP_TRY(hipGetLastError());
     return RDX_OK;
 }

@@ -1,0 +1,87 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo process groups drive rag_dpo_amd.sharded.ShardedSearcher with a
+TEST-ONLY oracle shard; the merged result must be bit-identical to the single-shard oracle search."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleShard:
+    """test double of sharded.HipShard: same interface, CPU tensors, oracle arithmetic"""
+
+    def __init__(self, corpus_hat, row_offset):
+        self.rows = corpus_hat
+        self.off = row_offset
+        self.device = torch.device("cpu")
+
+    def search(self, queries, k, out_score, out_row, out_count):
+        from oracle import oracle as O
+        s, r, c = O.cosine_topk(self.rows, queries.numpy(), k)
+        out_score.copy_(torch.from_numpy(s))
+        out_row.copy_(torch.from_numpy(np.where(r >= 0, r + self.off, -1)))
+        out_count.copy_(torch.from_numpy(c))
+
+    def merge_packed(self, packed, part_stride, n_parts, nq, k, out_score, out_row, out_count):
+        from oracle import oracle as O
+        from rag_dpo_amd.sharded import ShardedSearcher
+        parts = [ShardedSearcher.views(packed[p * part_stride:(p + 1) * part_stride], nq, k) for p in range(n_parts)]
+        s, r, c = O.merge_topk(np.stack([p[0].numpy() for p in parts]), np.stack([p[1].numpy() for p in parts]),
+                               np.stack([p[2].numpy() for p in parts]), k)
+        out_score.copy_(torch.from_numpy(s)); out_row.copy_(torch.from_numpy(r)); out_count.copy_(torch.from_numpy(c))
+
+
+def _worker(rank, world, port, n, dim, b, k, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from rag_dpo_amd import synth
+    from rag_dpo_amd.sharded import ShardedSearcher, shard_range
+    corpus = O.normalize_rows(synth.make_corpus(n, dim))
+    q = torch.from_numpy(synth.make_queries(b, dim, corpus))
+    lo, hi = shard_range(n, world, rank)
+    ss = ShardedSearcher(OracleShard(corpus[lo:hi], lo))
+    s, r, c = ss.search(q, k)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), c=c.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 3000), (3, 1001)])
+def test_sharded_search_matches_single(tmp_path, oracle, world, n):
+    from rag_dpo_amd import synth
+    dim, b, k = 128, 12, 10
+    mp.spawn(_worker, args=(world, _free_port(), n, dim, b, k, str(tmp_path)), nprocs=world, join=True)
+    corpus = oracle.normalize_rows(synth.make_corpus(n, dim))
+    q = synth.make_queries(b, dim, corpus)
+    es, er, ec = oracle.cosine_topk(corpus, q, k)
+    for rank in range(world):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        np.testing.assert_array_equal(got["r"], er)
+        np.testing.assert_array_equal(got["s"], es)
+        np.testing.assert_array_equal(got["c"], ec)
+
+
+def test_shard_range_covers_everything():
+    from rag_dpo_amd.sharded import shard_range
+    for n in (0, 1, 7, 8, 1000, 10_000_000):
+        for w in (1, 2, 3, 8):
+            edges = [shard_range(n, w, r) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
