@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Captures tests/golden/retriever_golden.json by driving the reference's OWN RAGRetriever
+(/root/reference/src/rag/retriever.py, imported here, never copied) with this repo's Chroma-shaped Collection
+and a deterministic embedder. Runs only in the build container (the reference does not travel to the GPU box);
+the JSON it writes is the committed fixture. `rank_bm25` (absent here) is stubbed in sys.modules before the import,
+as SURVEY.md §8c records; BM25 indexes are passed as None, so the stub is never called.
+
+    python tests/golden/make_retriever_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+
+stub = types.ModuleType("rank_bm25")
+stub.BM25Okapi = type("BM25Okapi", (), {"__init__": lambda self, *a, **k: None})
+sys.modules["rank_bm25"] = stub
+sys.path.insert(0, "/root/reference")
+from src.rag.retriever import RAGRetriever, reciprocal_rank_fusion, RetrievedChunk  # noqa: E402  (the reference)
+from src.rag.pipeline import build_enterprise_where_filter  # noqa: E402
+
+import fixture_world as W  # noqa: E402
+from oracle_engine import factory  # noqa: E402
+
+
+class Recorder:
+    """wraps the collection to record what the reference retriever sends to collection.query"""
+
+    def __init__(self, col):
+        self.col, self.seen = col, []
+
+    def query(self, **kw):
+        self.seen.append({"n_results": kw.get("n_results"), "where": kw.get("where"), "include": kw.get("include"),
+                          "n_query_embeddings": len(kw["query_embeddings"]), "dim": len(kw["query_embeddings"][0])})
+        return self.col.query(**kw)
+
+    def __getattr__(self, name):
+        return getattr(self.col, name)
+
+
+class Expander:
+    def expand(self, q):
+        return W.expander(q)
+
+
+def chunk_dict(c):
+    return {"chunk_id": c.chunk_id, "distance": c.distance, "semantic_score": c.semantic_score,
+            "hybrid_score": c.hybrid_score, "document_path": c.document_path, "chunk_nature": c.chunk_nature,
+            "chunk_index": c.chunk_index, "confidence": c.confidence, "text": c.text}
+
+
+def main():
+    out = {"generator": "tests/golden/make_retriever_golden.py driving /root/reference/src/rag/retriever.py",
+           "rrf_known_answer": reciprocal_rank_fusion([["a", "b", "c"], ["b", "d"]], weights=[2.0, 1.5]),
+           "similarity_of_distance_0.25": RetrievedChunk("x", "", "", "", 0, "", 0.25, {}).similarity_score,
+           "where_builder": [
+               {"base": None, "tags": None, "out": build_enterprise_where_filter(None, None)},
+               {"base": {"chunk_nature": {"$in": ["GUIDE"]}}, "tags": [], "out": build_enterprise_where_filter({"chunk_nature": {"$in": ["GUIDE"]}}, [])},
+               {"base": None, "tags": ["rh", "it"], "out": build_enterprise_where_filter(None, ["rh", "it"])},
+               {"base": {"chunk_nature": {"$in": ["GUIDE"]}}, "tags": ["rh"], "out": build_enterprise_where_filter({"chunk_nature": {"$in": ["GUIDE"]}}, ["rh"])},
+           ],
+           "cases": []}
+    for expand in (False, True):
+        for case in W.CASES:
+            rec = Recorder(W.build_collection(factory))
+            emb = W.HashEmbedder()
+            r = RAGRetriever(collection=rec, llm_provider=None, embedding_provider=emb, summary_bm25_index=None,
+                             chunk_bm25_index=None, query_expander=Expander() if expand else None)
+            cands = r.retrieve_candidates(case["query"], n_candidates=case["n_candidates"], where_filter=case["where"])
+            seen_c, embed_c = rec.seen, emb.calls
+            rec.seen, emb.calls = [], []
+            docs = r.retrieve(case["query"], where_filter=case["where"])
+            out["cases"].append({
+                "query": case["query"], "where": case["where"], "n_candidates": case["n_candidates"], "expand": expand,
+                "retrieve_candidates": {"collection_query_calls": seen_c, "embed_calls": embed_c,
+                                        "chunks": [chunk_dict(c) for c in cands]},
+                "retrieve": {"collection_query_calls": rec.seen, "embed_calls": emb.calls,
+                             "documents": [{"document_path": d.document_path, "avg_similarity": d.avg_similarity,
+                                            "primary_nature": d.primary_nature, "chunks": [chunk_dict(c) for c in d.chunks]}
+                                           for d in docs]},
+            })
+    with open(os.path.join(HERE, "retriever_golden.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False, indent=1)
+    print("wrote", len(out["cases"]), "cases")
+
+
+if __name__ == "__main__":
+    main()
