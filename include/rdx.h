@@ -76,7 +76,7 @@ int rdx_index_get(rdx_index* h, const int64_t* row_ids, int64_t n, float* out, i
 int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep);
 
 /* Options (tests and benchmarks): "force_exact" 0/1, "force_fast" 0/1 (MFMA scan even for small
- * problems), "sample_div" >=1, "cand_cap" 0 (auto) or >=64,
+ * problems), "sample_div" >=1, "cand_cap" 0 (auto) or slots per (query, stream) candidate segment,
  * "profile" 0/1 (record HIP events around every kernel of the next searches); "row_base" >= 0:
  * added to every returned row id, so a shard holding rows [base, base+count) answers with GLOBAL ids. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);

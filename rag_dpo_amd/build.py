@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdx.so")
 SOURCES = ["rdx_api.hip"]
-HEADERS = ["rdx_common.hpp", "k_rows.hpp", "k_scan.hpp", "k_refine.hpp", "../../include/rdx.h"]
+HEADERS = ["rdx_common.hpp", "k_rows.hpp", "scan_kernel.hpp", "refine_kernel.hpp", "../../include/rdx.h"]
 
 
 def _hipcc() -> str:

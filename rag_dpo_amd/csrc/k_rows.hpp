@@ -5,7 +5,8 @@
 
 namespace rdx {
 
-// write the 4 consecutive elements k..k+3 of a normalised row into the tiled fp16 copy
+// write the 4 consecutive elements k..k+3 of a normalised row into a scan copy (corpus: fragment order, queries: LDS images)
+template <bool QUERY>
 __device__ __forceinline__ void shadow_store4(_Float16* __restrict__ shadow, int64_t row, int k, int ksteps,
                                               float scale, float4 y) {
     half4 h;
@@ -13,13 +14,14 @@ __device__ __forceinline__ void shadow_store4(_Float16* __restrict__ shadow, int
     h[1] = (_Float16)(y.y * scale);
     h[2] = (_Float16)(y.z * scale);
     h[3] = (_Float16)(y.w * scale);
-    *reinterpret_cast<half4*>(shadow + shadow_off(row, k, ksteps)) = h;
+    *reinterpret_cast<half4*>(shadow + (QUERY ? query_off(row, k, ksteps) : corpus_off(row, k, ksteps))) = h;
 }
 
 // K1. out = in / max(|in|_2, 1e-12)  — SentenceTransformer.encode(normalize_embeddings=True),
 // reference src/utils/embedding_provider.py:139-145; also what `collection.add` needs for the cosine
 // space (reference src/processing/create_chromadb_index.py:100-106,374-379).
 // Destination row of input row i is dst_rows ? dst_rows[i] : row0 + i.
+template <bool QUERY>
 __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in, const uint16_t* __restrict__ in_bf16,
                                                    int64_t n, int dim, const int64_t* __restrict__ dst_rows,
                                                    int64_t row0, float* __restrict__ master,
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
         y.z = (float)((double)v.z / den);
         y.w = (float)((double)v.w / den);
         if (master) reinterpret_cast<float4*>(master + dst * (int64_t)dim)[g] = y;
-        if (shadow) shadow_store4(shadow, dst, 4 * g, ksteps, scale, y);
+        if (shadow) shadow_store4<QUERY>(shadow, dst, 4 * g, ksteps, scale, y);
     }
 }
 
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void k_reshadow(const float* __restrict__ mast
     const int64_t r = row0 + i;
     const int n4 = dim >> 2;
     for (int g = lane; g < n4; g += 64)
-        shadow_store4(shadow, r, 4 * g, ksteps, scale, reinterpret_cast<const float4*>(master + r * (int64_t)dim)[g]);
+        shadow_store4<false>(shadow, r, 4 * g, ksteps, scale, reinterpret_cast<const float4*>(master + r * (int64_t)dim)[g]);
 }
 
 // out[i] = master[rows[i]]  (collection.get(include=["embeddings"]), compaction)

@@ -12,9 +12,9 @@
 #include <string>
 #include <vector>
 
-#include "k_refine.hpp"
 #include "k_rows.hpp"
-#include "k_scan.hpp"
+#include "refine_kernel.hpp"
+#include "scan_kernel.hpp"
 
 using namespace rdx;
 
@@ -94,7 +94,7 @@ struct rdx_index {
     int64_t row_base = 0;   // added to every returned row id (global ids of a shard)
 
     // scratch (grow-only; never allocated inside a warmed-up search)
-    DevBuf staging, qraw, qhat, qshadow, tau, cnt, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
+    DevBuf staging, qraw, qhat, qshadow, tau, cntw, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
         o_count, mask, ids;
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
@@ -198,7 +198,7 @@ extern "C" int rdx_index_destroy(rdx_index* h) {
     (void)hipStreamSynchronize(h->own_stream);
     if (h->master) (void)hipFree(h->master);
     if (h->shadow) (void)hipFree(h->shadow);
-    for (DevBuf* b : {&h->staging, &h->qraw, &h->qhat, &h->qshadow, &h->tau, &h->cnt, &h->cand, &h->setmax, &h->exact_list,
+    for (DevBuf* b : {&h->staging, &h->qraw, &h->qhat, &h->qshadow, &h->tau, &h->cntw, &h->cand, &h->setmax, &h->exact_list,
                       &h->iota, &h->dense, &h->ctr, &h->bad, &h->o_score, &h->o_row, &h->o_count, &h->mask, &h->ids})
         b->release();
     if (h->ev_ok)
@@ -241,7 +241,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
         if (value < 0) return fail(RDX_ERR_INVALID, "row_base must be >= 0");
         h->row_base = value;
     } else if (n == "cand_cap") {
-        if (value != 0 && value < 64) return fail(RDX_ERR_INVALID, "cand_cap must be 0 (auto) or >= 64");
+        if (value < 0) return fail(RDX_ERR_INVALID, "cand_cap must be 0 (auto) or a positive slot count per (query, stream) segment");
         h->cand_cap = value;
     } else
         return fail(RDX_ERR_INVALID, "unknown option '" + n + "'");
@@ -269,7 +269,7 @@ static int ingest(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int s
             src = h->staging.as<char>();
         }
         const int grid = (int)((m + 3) / 4);
-        hipLaunchKernelGGL(k_normalize, dim3(grid), dim3(256), 0, st, is_bf16 ? nullptr : (const float*)src,
+        hipLaunchKernelGGL(k_normalize<false>, dim3(grid), dim3(256), 0, st, is_bf16 ? nullptr : (const float*)src,
                            is_bf16 ? (const uint16_t*)src : nullptr, m, h->dim, d_dst_ids ? d_dst_ids + off : nullptr,
                            row0 + off, h->master, h->shadow, h->ksteps, h->scale(), h->bad.as<int>());
         HIP_TRY(hipGetLastError());
@@ -418,7 +418,7 @@ extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim,
         d_out = bo.as<float>();
     }
     HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_normalize, dim3((int)((n + 3) / 4)), dim3(256), 0, st, d_in, (const uint16_t*)nullptr, n, dim,
+    hipLaunchKernelGGL(k_normalize<false>, dim3((int)((n + 3) / 4)), dim3(256), 0, st, d_in, (const uint16_t*)nullptr, n, dim,
                        (const int64_t*)nullptr, (int64_t)0, d_out, (_Float16*)nullptr, 0, 1.0f, bad.as<int>());
     HIP_TRY(hipGetLastError());
     int rc = RDX_OK;
@@ -440,27 +440,22 @@ extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim,
 // ------------------------------------------------------------------------------------------------
 // search
 // ------------------------------------------------------------------------------------------------
-template <int BN, int EPI>
+template <int BN, int EPI, bool RES>
 static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t st) {
-    const size_t lds = 2 * (size_t)(KSTEP_BYTES + BN * BK * 2);
-    if (p.allow) {
-        auto kern = k_scan<BN, EPI, true>;
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
-    } else {
-        auto kern = k_scan<BN, EPI, false>;
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
-    }
+    // LDS: query-image ring (or the whole resident query tile) + BN hit counters
+    const size_t lds = (size_t)(RES ? p.ksteps : RING_SLOTS) * BN * BK * 2 + BN * 4;
+    void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES> : k_scan<BN, EPI, false, RES>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
     HIP_TRY(hipGetLastError());
     return RDX_OK;
 }
 
 template <int EPI>
-static int launch_scan_bn(rdx_index* h, int bn, const ScanParams& p, int grid, hipStream_t st) {
-    if (bn == 64) return launch_scan<64, EPI>(h, p, grid, st);
-    if (bn == 128) return launch_scan<128, EPI>(h, p, grid, st);
-    return launch_scan<256, EPI>(h, p, grid, st);
+static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, int grid, hipStream_t st) {
+    if (bn == 64) return res ? launch_scan<64, EPI, true>(h, p, grid, st) : launch_scan<64, EPI, false>(h, p, grid, st);
+    if (bn == 128) return launch_scan<128, EPI, false>(h, p, grid, st);
+    return launch_scan<256, EPI, false>(h, p, grid, st);
 }
 
 static const int K_FAST_MAX = 256;   // larger k goes through the exact full scan
@@ -501,7 +496,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     HIP_TRY(hipMemsetAsync(h->bad.p, 0, sizeof(int), st));
     HIP_TRY(hipMemsetAsync(h->ctr.p, 0, sizeof(RefineCounters), st));
     if (nq != nq_pad || h->dim != h->dim_pad) HIP_TRY(hipMemsetAsync(h->qshadow.p, 0, (size_t)nq_pad * h->dim_pad * 2, st));
-    hipLaunchKernelGGL(k_normalize, dim3((int)((nq + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
+    hipLaunchKernelGGL(k_normalize<true>, dim3((int)((nq + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
                        (const int64_t*)nullptr, (int64_t)0, h->qhat.as<float>(), h->qshadow.as<_Float16>(), h->ksteps, h->scale(),
                        h->bad.as<int>());
     HIP_TRY(hipGetLastError());
@@ -530,19 +525,28 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         if (nqt > wpx) return fail(RDX_ERR_STATE, "internal: query chunk larger than one scan launch");
         const int G = wpx / nqt;
         const int n_streams = 8 * G;
-        const int wm = 8 / (bn / 64);
-        const int n_sets = n_streams * wm * SETS_PER_WAVE;
+        if (n_streams > REFINE_STREAMS) return fail(RDX_ERR_STATE, "internal: more streams than the refine kernel gathers");
+        const int n_sets = n_streams * SETS_PER_STREAM;
         const int64_t n_tiles = (h->rows + 255) / 256;
-        // bootstrap sample: every div-th tile, at least ~max(64k, 8192) rows when the corpus has them
+        if (n_tiles * h->ksteps >= ((int64_t)1 << 31)) return fail(RDX_ERR_STATE, "shard too large for one scan launch");
+        // the 64-query tile stays resident in LDS when all its k-step images fit (no DMA, no barrier in the main loop)
+        const bool res = bn == 64 && (size_t)h->ksteps * 8192 + 256 <= 160 * 1024 - 1024;
+        // bootstrap sample: every div-th tile. More rows sampled = tighter tau = fewer hits; keep the expected hits
+        // per query (~1.3 k rows/sample_rows) around 4000/... of the refine list and the sample >= max(64k, 8192) rows
         const int64_t want_rows = std::max<int64_t>(64 * (int64_t)k, 8192);
-        int div = (int)std::max<int64_t>(1, std::min<int64_t>(h->sample_div, h->rows / want_rows));
-        sample_rows = (n_tiles + div - 1) / div * 256;
-        uint32_t cap = (uint32_t)(h->cand_cap ? h->cand_cap : std::max<int64_t>(2048, 128 * (int64_t)k));
+        int div = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(h->sample_div, h->rows / want_rows), 3000 / std::max(k, 1)));
+        const int64_t n_sched = (n_tiles + div - 1) / div;
+        sample_rows = n_sched * 256;
+        const int n_sets_used = (int)std::min<int64_t>(n_streams, n_sched) * SETS_PER_STREAM;
+        // slots per (query, stream) segment: 8x the expected hits, power of two, [32, 4096]
+        const double exp_hits = (1.5 * k * (double)h->rows / (double)std::max<int64_t>(sample_rows, 1) + k) / n_streams;
+        uint32_t capw = 32;
+        while (capw < 4096 && capw < 8.0 * exp_hits) capw *= 2;
+        if (h->cand_cap) capw = (uint32_t)std::min<int64_t>(h->cand_cap, 1 << 16);
         RDX_TRY(h->tau.ensure((size_t)nq_pad * 4));
-        RDX_TRY(h->cnt.ensure((size_t)nq_pad * 4));
-        RDX_TRY(h->cand.ensure((size_t)nq_pad * cap * 8));
+        RDX_TRY(h->cntw.ensure((size_t)nq_pad * n_streams * 4));
+        RDX_TRY(h->cand.ensure((size_t)nq_pad * n_streams * capw * 8));
         RDX_TRY(h->setmax.ensure((size_t)nq_pad * n_sets * 4));
-        HIP_TRY(hipMemsetAsync(h->cnt.p, 0, (size_t)nq_pad * 4, st));
 
         ScanParams p = {};
         p.shadow = h->shadow;
@@ -556,25 +560,29 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         p.setmax = h->setmax.as<float>();
         p.n_sets = n_sets;
         p.tau = h->tau.as<float>();
-        p.cnt = h->cnt.as<uint32_t>();
+        p.cntw = h->cntw.as<uint32_t>();
         p.cand = h->cand.as<uint2>();
-        p.cap = cap;
+        p.capw = capw;
         p.inv_scale2 = std::ldexp(1.0f, -2 * h->scale_log2);
 
         p.tile_stride = div;
-        RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn, p, grid, st));
+        RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn, res, p, grid, st));
         mark(2);
-        hipLaunchKernelGGL(k_tau, dim3(nq_pad), dim3(256), 0, st, h->setmax.as<float>(), n_sets, k,
+        hipLaunchKernelGGL(k_tau, dim3(nq_pad), dim3(256), 0, st, h->setmax.as<float>(), n_sets, n_sets_used, k,
                            h->two_e() * std::ldexp(1.0f, 2 * h->scale_log2), (int)nq, h->tau.as<float>());
         HIP_TRY(hipGetLastError());
         mark(3);
         p.tile_stride = 1;
-        RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, p, grid, st));
+        RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, res, p, grid, st));
         mark(4);
-        hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(256), 0, st, h->cand.as<uint2>(), h->cnt.as<uint32_t>(), cap, k, h->two_e(),
-                           h->qhat.as<float>(), h->master, h->dim, h->row_base, d_score, d_row, d_count,
-                           h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
-        HIP_TRY(hipGetLastError());
+        {
+            const size_t lds = (size_t)REFINE_LIST * 8;
+            HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(256), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
+                               k, h->two_e(), h->qhat.as<float>(), h->master, h->dim, h->row_base, d_score, d_row, d_count,
+                               h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
+            HIP_TRY(hipGetLastError());
+        }
         mark(5);
         HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -1,15 +1,17 @@
 // rdx_common.hpp — shared device helpers and the HBM layouts of librdx (gfx950 only).
 //
 // HBM layout of one corpus shard (all owned by rdx_index, see rdx_api.hip):
-//   master  fp32 [cap_rows][dim]            row-major L2-normalised rows; the exact re-score reads it
-//   shadow  fp16 [cap_rows/256][dim_pad/64][256 rows][64 k]   "scan copy": value = master * 2^scale_log2,
-//           one 32 KiB image per (256-row tile, 64-wide k-step), stored in the exact byte order the MFMA
-//           scan kernel wants in LDS, so a k-step is ONE contiguous 32 KiB stream from HBM and the
-//           global->LDS DMA (global_load_lds_dwordx4) needs no per-lane address arithmetic.
-//           Inside an image row r (128 B = eight 16-B chunks) chunk c sits in slot c ^ ((r >> 1) & 7):
-//           the XOR makes the ds_read_b128 fragment reads of 16 different rows hit 16 different 16-B
-//           bank slots (conflict-free), cf. cdna_hip_programming.md T2 / rule 21 (swizzle is applied
-//           where the image is WRITTEN, i.e. once at ingest, and again on the LDS read address).
+//   master  fp32 [cap_rows][dim]   row-major L2-normalised rows; the exact re-score and the exact scan read it
+//   shadow  fp16 "scan copy", value = master * 2^scale_log2, stored in MFMA FRAGMENT ORDER:
+//           [row block rb = row/32][k chunk kc = k/16][lane 0..63][8 halfs]
+//           lane l of chunk (rb, kc) holds row rb*32 + (l & 31), k = kc*16 + 8*(l >> 5) + 0..7 — exactly the A operand
+//           of v_mfma_f32_32x32x16_f16. One chunk = 1 KiB = one fully coalesced global_load_dwordx4 of a wavefront,
+//           and all chunks of a 32-row block are contiguous (dim_pad/16 KiB): a wave streams its rows straight from
+//           HBM into VGPRs, no LDS, no address arithmetic beyond "+1 KiB".
+//   query scan copy (per search): [query block of 256][k-step ks = k/64][256 rows][64 k] fp16, i.e. one 32 KiB LDS image
+//           per (block, k-step). Inside an image row r (128 B = eight 16-B chunks) chunk c sits in slot c ^ ((r >> 1) & 7):
+//           the XOR makes the ds_read_b128 fragment reads of 16 different rows hit 16 different 16-B bank slots
+//           (conflict-free; cdna_hip_programming.md T2 / rule 21: swizzle where the image is written and on the read).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,8 +28,16 @@ constexpr int KSTEP_BYTES = TILE_ROWS * BK * 2;   // 32 KiB
 constexpr int MAX_DIM = 4096;
 constexpr int SETS_PER_WAVE = 32;                 // threshold-bootstrap sets per (stream, wave row)
 
-// offset (in halfs) of element (row r, column k) inside the tiled fp16 copy
-__host__ __device__ inline int64_t shadow_off(int64_t r, int k, int ksteps) {
+// offset (in halfs) of element (row r, column k) inside the fragment-ordered corpus scan copy
+__host__ __device__ inline int64_t corpus_off(int64_t r, int k, int ksteps) {
+    const int64_t rb = r >> 5;
+    const int kc = k >> 4;
+    const int lane = (int)(r & 31) + (((k & 15) >> 3) << 5);
+    return ((rb * (ksteps * 4) + kc) * 64 + lane) * 8 + (k & 7);
+}
+
+// offset (in halfs) of element (query r, column k) inside the tiled + swizzled query scan copy
+__host__ __device__ inline int64_t query_off(int64_t r, int k, int ksteps) {
     const int64_t blk = r >> 8;
     const int rr = (int)(r & 255);
     const int ks = k >> 6;

@@ -1,11 +1,13 @@
-// k_refine.hpp — K4: exact re-score + final ordering of the scan's candidates, and C1's merge of per-shard
+// refine_kernel.hpp — K4: exact re-score + final ordering of the scan's candidates, and C1's merge of per-shard
 // partial results after the RCCL all-gather.
 #pragma once
 #include "k_rows.hpp"
 
 namespace rdx {
 
-constexpr int REFINE_PMAX = 1024;   // most candidates re-scored exactly per query; more -> exact full scan
+constexpr int REFINE_PMAX = 1024;    // most candidates re-scored exactly per query; more -> exact full scan
+constexpr int REFINE_LIST = 8192;    // most scan hits gathered per query (64 KiB of LDS); more -> exact full scan
+constexpr int REFINE_STREAMS = 512;  // most (query, stream) segments
 
 struct RefineCounters {   // one per index, zeroed before every search
     unsigned long long emitted;
@@ -15,28 +17,50 @@ struct RefineCounters {   // one per index, zeroed before every search
 };
 
 // One block (256 threads) per query.
-//   cand[q][0..cnt) = (coarse score, row) of every allowed row whose coarse score >= tau[q].
-//   c_k = k-th largest coarse score. Every true top-k row has coarse >= c_k - 2E (|coarse-exact| <= E and k rows
-//   reach coarse c_k, hence exact c_k - E), so P = {coarse >= c_k - 2E} contains the exact top-k; P is re-scored
-//   exactly from the fp32 master copy (fp64 lane-order sum, oracle/rdx_oracle.c) and ranked (score desc, row asc).
-//   Overflow of the candidate list or of P cannot be answered here: the query is flagged for the exact scan.
-__global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cnt,
-                                                uint32_t cap, int k, float two_e, const float* __restrict__ qhat,
-                                                const float* __restrict__ master, int dim, int64_t row_base,
-                                                float* __restrict__ out_score, int64_t* __restrict__ out_row,
+//   The scan left, per (query, stream), cntw hits in a segment of capw slots: (coarse score, row) of every allowed row
+//   whose coarse score >= tau[q]. They are gathered into LDS; c_k = k-th largest coarse score. Every true top-k row has
+//   coarse >= c_k - 2E (|coarse-exact| <= E and k rows reach coarse c_k, hence exact c_k - E), so
+//   P = {coarse >= c_k - 2E} contains the exact top-k; P is re-scored exactly from the fp32 master copy (fp64 lane-order
+//   sum, oracle/rdx_oracle.c) and ranked (score desc, row asc).
+//   A segment, list or P overflow cannot be answered here: the query is flagged for the exact full scan.
+__global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
+                                                int n_streams, uint32_t capw, int k, float two_e,
+                                                const float* __restrict__ qhat, const float* __restrict__ master, int dim,
+                                                int64_t row_base, float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                 int32_t* __restrict__ out_count, int32_t* __restrict__ exact_list,
                                                 RefineCounters* __restrict__ ctr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2* list = reinterpret_cast<uint2*>(smem);                        // [REFINE_LIST]
     __shared__ uint32_t hist[256];
     __shared__ uint32_t bc[4];
+    __shared__ uint32_t seg_off[REFINE_STREAMS + 1];
     __shared__ float s_s[REFINE_PMAX];
     __shared__ int64_t s_r[REFINE_PMAX];
-    __shared__ int n_p;
+    __shared__ int n_p, overflow;
     const int q = blockIdx.x;
-    const uint32_t m = cnt[q];
     float* o_s = out_score + (int64_t)q * k;
     int64_t* o_r = out_row + (int64_t)q * k;
+    if (threadIdx.x == 0) overflow = 0;
+    __syncthreads();
+    // segment sizes -> exclusive prefix (n_streams <= 512: two per thread, serial scan by one wave is plenty)
+    for (int w = threadIdx.x; w < n_streams; w += blockDim.x) {
+        const uint32_t c = cntw[(int64_t)q * n_streams + w];
+        if (c > capw) overflow = 1;
+        seg_off[w + 1] = c > capw ? capw : c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        seg_off[0] = 0;
+        for (int w = 0; w < n_streams; ++w) {
+            acc += seg_off[w + 1];
+            seg_off[w + 1] = acc;
+        }
+    }
+    __syncthreads();
+    const uint32_t m = seg_off[n_streams];
     if (threadIdx.x == 0) atomicAdd(&ctr->emitted, (unsigned long long)m);
-    if (m > cap) {
+    if (overflow || m > REFINE_LIST) {
         if (threadIdx.x == 0) exact_list[atomicAdd(&ctr->n_exact, 1)] = q;
         return;
     }
@@ -44,15 +68,21 @@ __global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, 
         rank_and_write(s_s, s_r, 0, k, o_s, o_r, out_count + q);
         return;
     }
-    const uint2* c = cand + (int64_t)q * cap;
+    // gather: thread w walks segment w (independent loads across threads)
+    for (int w = threadIdx.x; w < n_streams; w += blockDim.x) {
+        const uint32_t a = seg_off[w], b = seg_off[w + 1];
+        const uint2* seg = cand + ((int64_t)q * n_streams + w) * capw;
+        for (uint32_t i = a; i < b; ++i) list[i] = seg[i - a];
+    }
+    __syncthreads();
     const int64_t kk = (uint32_t)k < m ? k : m;
     int64_t n_gt;
-    const uint32_t kth = block_kth_largest([&](int64_t i) { return f2key(__uint_as_float(c[i].x)); }, m, kk, hist, bc, &n_gt);
+    const uint32_t kth = block_kth_largest([&](int64_t i) { return f2key(__uint_as_float(list[i].x)); }, m, kk, hist, bc, &n_gt);
     const float t2 = key2f(kth) - two_e;
     if (threadIdx.x == 0) n_p = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
-        const uint2 e = c[i];
+        const uint2 e = list[i];
         if (__uint_as_float(e.x) >= t2) {
             const int pos = atomicAdd(&n_p, 1);
             if (pos < REFINE_PMAX) s_r[pos] = (int64_t)e.y;
@@ -80,9 +110,9 @@ __global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, 
 }
 
 // C1. merge n_parts partial top-k lists per query. One block per query; n_parts*k <= MERGE_MAX.
-constexpr int MERGE_MAX = 4096;
 // part p of each array starts stride_* ELEMENTS after part p-1 (contiguous [n_parts][nq][k] arrays, or the
 // packed all-gather receive buffer).
+constexpr int MERGE_MAX = 4096;
 __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ part_score, const int64_t* __restrict__ part_row,
                                                const int32_t* __restrict__ part_count, int64_t stride_s, int64_t stride_r,
                                                int64_t stride_c, int n_parts, int64_t nq, int k,

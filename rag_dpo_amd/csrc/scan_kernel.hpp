@@ -1,0 +1,356 @@
+// scan_kernel.hpp — K2+K3: the corpus scan. fp16 MFMA GEMM  S[row][query] = <corpus row, query>  over the
+// fragment-ordered scan copy, with the top-k work fused into the epilogue so the B x N score matrix never exists in HBM.
+//
+// Roofline: reads rows*dim_pad*2 B of corpus exactly once per launch (HBM) and does 2*rows*nq*dim_pad flop
+// (MFMA). HBM-bound while nq per sweep is small, MFMA-bound from nq ~ 300 up.
+//
+// Dataflow (one workgroup = 8 waves = one 256-row corpus tile x BN queries per step, persistent over a stream of tiles):
+//   corpus  HBM --global_load_dwordx4 (1 KiB per wave-instruction, fragment order)--> VGPRs of the ONE wave that owns those
+//           32 rows. No LDS, no sharing between waves, prefetched two k-steps ahead into the registers the matrix pipe
+//           has just finished reading.
+//   queries L2 --LDS-DMA (global_load_lds_dwordx4)--> 3-slot LDS ring of (BN x 64 k) images shared by the 8 waves, filled
+//           two k-steps ahead; when all k-steps of a 64-query tile fit (<= 128 KiB) the tile stays RESIDENT in LDS and
+//           the main loop has no DMA and no barrier at all (the HBM-bound small-batch regime).
+//   MFMA    v_mfma_f32_32x32x16_f16, corpus fragment = A operand, query fragment = B operand: D[row][query] has the QUERY
+//           on the lane (col = lane & 31) and 16 corpus rows in the 16 accumulator registers, so the per-query threshold
+//           lives in one register per lane and the epilogue is compare-only.
+//   The nqt query tiles of one stream run on workgroups with equal blockIdx % 8, i.e. on one XCD, so a corpus tile is
+//   fetched from HBM once and re-read from that XCD's L2 (speed only — nothing depends on the placement).
+//
+// Synchronisation per k-step: ONE s_waitcnt vmcnt(V) (V = loads issued during the previous step, which stay in flight)
+// and, in ring mode, ONE s_barrier that never waits for memory: everything a step needs was issued two steps earlier.
+// The corpus loads are inline asm (the compiler would drain vmcnt(0) at their first use next to LDS-DMA,
+// cdna_hip_programming.md §5 trap (b)); their destination registers are handed to the compiler only through the
+// "+v" operands of the wait statement (§5.7 form (ii)).
+//
+// Epilogues.
+//   EPI_SETMAX (threshold bootstrap, run on every sample_div-th tile): accumulator register positions keep a running max
+//     over all tiles of the stream -> 8 disjoint row sets per (stream, wave) and query. k_tau takes the k-th
+//     largest set max: k DISTINCT rows score at least that, which makes tau = that - 2E a lower bound for every true
+//     top-k row's coarse score (E = |coarse - exact| bound).
+//   EPI_EMIT (main pass): every (row, query) whose coarse score >= tau[query] is appended to the (query, stream) candidate
+//     segment: slot from an LDS counter (no global atomics, no round trip), 8-byte fire-and-forget store.
+#pragma once
+#include "rdx_common.hpp"
+
+namespace rdx {
+
+constexpr int EPI_SETMAX = 0;
+constexpr int EPI_EMIT = 1;
+constexpr int SETS_PER_STREAM = 64;   // bootstrap sets per (stream, query): 8 waves x 2 lane halves x 4 register classes
+constexpr int RING_SLOTS = 3;
+
+struct ScanParams {
+    const _Float16* shadow;    // fragment-ordered corpus scan copy
+    const _Float16* qshadow;   // tiled query scan copy
+    int ksteps;                // dim_pad / 64
+    int64_t rows;              // valid corpus rows
+    int64_t n_tiles;           // ceil(rows / 256)
+    int tile_stride;           // 1 (main) or sample_div (bootstrap): tiles 0, stride, 2*stride, ...
+    int nqt;                   // query tiles of BN queries
+    int nq_pad;                // queries padded to 256
+    const uint32_t* allow;     // NULL or row bitmap
+    // EPI_SETMAX
+    float* setmax;             // [nq_pad][n_sets], n_sets = n_streams * SETS_PER_STREAM
+    int n_sets;
+    // EPI_EMIT
+    const float* tau;          // [nq_pad] in accumulator units (score * 4^scale_log2)
+    uint32_t* cntw;            // [nq_pad][n_streams] hits of (query, stream); a value above capw means overflow
+    uint2* cand;               // [nq_pad][n_streams][capw] (score bits, row)
+    uint32_t capw;
+    float inv_scale2;          // accumulator -> score
+};
+
+// row inside a 32x32 MFMA block held by accumulator register r of a lane in half h (= lane >> 5)
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// 16 B per lane straight into VGPRs; completion is the CALLER's business (counted s_waitcnt vmcnt)
+__device__ __forceinline__ void gload16(half8& dst, const char* addr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+}
+
+// all but the N newest vector-memory operations of this wave are complete; the fragments become visible to the compiler
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_keep(half8 (&a)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory");
+}
+
+template <int BN, int EPI, bool HAS_MASK, bool RES>
+__global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
+    constexpr int NBN = BN / 32;          // 32-query blocks per wave (a wave owns 32 rows x all BN queries)
+    constexpr int B_BYTES = BN * BK * 2;  // one k-step image of this workgroup's queries
+    constexpr int NPB = BN / 64;          // 1 KiB DMA pieces per wave per query image
+    constexpr int V = 4 + (RES ? 0 : NPB);   // vector-memory operations a wave issues per k-step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- which stream / query tile am I (XCD-aware: blocks with equal blockIdx % 8 share an L2) ----
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
+    const int wpx = gridDim.x >> 3;
+    const int G = wpx / p.nqt;           // streams per XCD
+    if (slot >= G * p.nqt) return;
+    const int qt = slot % p.nqt;
+    const int stream = xcd * G + slot / p.nqt;
+    const int n_streams = 8 * G;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int n_sched = (int)((p.n_tiles + p.tile_stride - 1) / p.tile_stride);   // tiles in this launch
+    const int my_tiles = stream < n_sched ? (n_sched - stream + n_streams - 1) / n_streams : 0;
+    const int KS = p.ksteps;
+    const int total = my_tiles * KS;   // k-steps of this workgroup (host keeps tiles*ksteps < 2^31)
+
+    const int ring_bytes = (RES ? KS : RING_SLOTS) * B_BYTES;
+    uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + ring_bytes);   // [BN] hit counters of this (stream, query tile)
+    if constexpr (EPI == EPI_EMIT) {
+        for (int i = threadIdx.x; i < BN; i += 512) lcnt[i] = 0;
+    }
+
+    // query images of this tile: [ks][BN rows][128 B], rows (qt*BN)%256.. of the 256-row block qt*BN/256
+    const char* qbase = reinterpret_cast<const char*>(p.qshadow) + ((int64_t)(qt * BN / 256) * KS) * KSTEP_BYTES +
+                        (int64_t)((qt * BN) % 256) * 128 + wave * (NPB * 1024) + lane * 16;
+    auto issue_b = [&](int ks_i, int slot_i) {   // this wave's pieces of query image ks_i -> LDS slot slot_i
+        const char* src = qbase + (int64_t)ks_i * KSTEP_BYTES;
+        char* dst = smem + slot_i * B_BYTES + wave * (NPB * 1024);
+#pragma unroll
+        for (int i = 0; i < NPB; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+    // corpus fragments of (tile iteration it, k-step ks): 4 consecutive 1 KiB chunks of this wave's 32-row block
+    const int64_t rb_bytes = (int64_t)KS * 4096;   // bytes of one 32-row block in the scan copy
+    auto a_src = [&](int it_i, int ks_i) -> const char* {
+        const int64_t tile = (int64_t)(stream + it_i * n_streams) * p.tile_stride;
+        return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096 + lane * 16;
+    };
+
+    f32x16 acc[NBN];
+#pragma unroll
+    for (int n = 0; n < NBN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    // per-lane epilogue state
+    float runmax[EPI == EPI_SETMAX ? NBN : 1][4];
+    float tau_l[EPI == EPI_EMIT ? NBN : 1];
+    const int qcol0 = qt * BN + l31;   // query of n-block 0; n-block n is +32 n
+    if constexpr (EPI == EPI_SETMAX) {
+#pragma unroll
+        for (int n = 0; n < NBN; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) runmax[n][j] = -INFINITY;
+    } else {
+#pragma unroll
+        for (int n = 0; n < NBN; ++n) tau_l[n] = p.tau[qcol0 + n * 32];
+#pragma unroll
+        for (int n = 0; n < NBN; ++n) asm volatile("" : "+v"(tau_l[n]));   // compiler-visible loads are complete before the hand-counted vmcnt region
+    }
+
+    // LDS address of this lane's query fragment for k sub-step kk (n-block n adds n*4096): row l31, chunk 2kk+half, swizzled
+    const int b_sw = ((((qt * BN) % 256) + l31) >> 1) & 7;   // identical for every n-block (32 rows = 4 swizzle periods)
+    int b_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) b_off[kk] = l31 * 128 + (((kk * 2 + half) ^ b_sw) << 4);
+
+    if (total > 0) {
+        half8 a0[4], a1[4];   // corpus fragments of the even / odd k-steps in flight
+        // ---- prologue: steps 0 and 1 in flight (order matters for the counted waits: B(0) A(0) B(1) A(1)) ----
+        if constexpr (RES) {
+            for (int ks_i = 0; ks_i < KS; ++ks_i) issue_b(ks_i, ks_i);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        } else {
+            issue_b(0, 0);
+        }
+        {
+            const char* s0 = a_src(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) gload16(a0[kk], s0 + kk * 1024);
+        }
+        int it1 = 0, ks1 = 1;
+        if (ks1 == KS) { ks1 = 0; it1 = 1; }
+        // Every step issues its V loads unconditionally (steps that do not exist re-read the stream's first step: valid
+        // memory, never consumed) so that the counted waits stay uniform and no conditional copy of an in-flight
+        // register is ever needed. An asm load must not be in flight towards a register the compiler considers dead
+        // (it would reuse the register and the late write-back would corrupt it): both fragment sets are kept alive
+        // until the final s_waitcnt vmcnt(0) below.
+        const bool have1 = total > 1;
+        if constexpr (!RES) issue_b(have1 ? ks1 : 0, 1);
+        {
+            const char* s1 = a_src(have1 ? it1 : 0, have1 ? ks1 : 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) gload16(a1[kk], s1 + kk * 1024);
+        }
+
+        int it = 0, ks = 0;            // step being computed
+        int it2 = it1, ks2 = ks1 + 1;  // step s+2 (prefetched during step s)
+        if (ks2 >= KS) { ks2 -= KS; ++it2; }
+        int slot_c = 0, slot_p = 2;    // ring slot of step s / of step s+2
+
+        auto step = [&](half8 (&af)[4], int s) {
+            // (1) everything issued before the previous step has landed: this step's corpus fragments (mine) and my pieces
+            //     of its query image; the V operations of the previous step stay in flight
+            wait_vmcnt_keep<V>(af);
+            if constexpr (!RES) __builtin_amdgcn_s_barrier();   // ... for every wave; also: all waves are done with step s-1
+            const char* st = smem + (RES ? ks : slot_c) * B_BYTES;
+            const bool more = s + 2 < total;   // step s+2 exists; otherwise re-read this stream's first step (never used)
+            const int pks = more ? ks2 : 0;
+            const char* an = a_src(more ? it2 : 0, pks);
+            // The step's 4*NBN MFMAs run as groups of GB query blocks; the query fragments of group g+1 are read from LDS
+            // right behind the first MFMA of group g (register double buffer of GB fragments: their latency hides under
+            // the remaining MFMAs of the group). Issue order pinned with sched_barrier(0).
+            constexpr int GB = NBN < 4 ? NBN : 4;
+            constexpr int GPK = NBN / GB;          // groups per k sub-step
+            constexpr int NG = 4 * GPK;            // groups per step
+            half8 bf[2][GB];
+            auto load_group = [&](int g, half8 (&dst)[GB]) {
+                const int kk = g / GPK, nb0 = (g % GPK) * GB;
+#pragma unroll
+                for (int j = 0; j < GB; ++j) dst[j] = *reinterpret_cast<const half8*>(st + b_off[kk] + (nb0 + j) * 4096);
+            };
+            load_group(0, bf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int kk = g / GPK, nb0 = (g % GPK) * GB;
+#pragma unroll
+                for (int j = 0; j < GB; ++j) {
+                    acc[nb0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[g & 1][j], acc[nb0 + j], 0, 0, 0);
+                    if (j == 0 && g + 1 < NG) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_group(g + 1, bf[(g + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if ((g % GPK) == GPK - 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the matrix pipe has read af[kk]: refill it with the fragment of step s+2 (lands during the next step)
+                    gload16(af[kk], an + kk * 1024);
+                    if constexpr (!RES) {
+                        if (kk == 0) issue_b(pks, slot_p);   // query image of step s+2 into the slot step s-1 just released
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+
+        auto epilogue = [&](int it_done) {
+            const int64_t tile = (int64_t)(stream + it_done * n_streams) * p.tile_stride;
+            const int64_t row_b = tile * TILE_ROWS + wave * 32;   // first row of this wave's 32-row block
+            const bool ragged = (tile + 1) * TILE_ROWS > p.rows;  // tile holds padding rows
+            uint32_t okbits = 0xffffffffu;                        // bit i: row row_b+i may be used
+            if (ragged) {
+                const int64_t left = p.rows - row_b;
+                okbits = left >= 32 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << left) - 1u));
+            }
+            if constexpr (HAS_MASK) {
+                if (row_b < p.rows) okbits &= p.allow[row_b >> 5];
+            }
+            const bool filt = HAS_MASK || ragged;
+#pragma unroll
+            for (int n = 0; n < NBN; ++n) {
+                if constexpr (EPI == EPI_SETMAX) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[n][r];
+                        if (filt && !((okbits >> acc_row(r, half)) & 1u)) v = -INFINITY;
+                        runmax[n][r & 3] = fmaxf(runmax[n][r & 3], v);
+                    }
+                } else {
+                    float mx = acc[n][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[n][r]);
+                    if (__any(mx >= tau_l[n])) {
+                        const int ql = n * 32 + l31;
+                        uint2* seg = p.cand + ((int64_t)(qt * BN + ql) * n_streams + stream) * p.capw;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = acc[n][r];
+                            const int rib = acc_row(r, half);
+                            if (v >= tau_l[n] && (!filt || ((okbits >> rib) & 1u))) {
+                                // LDS counter: no global round trip. Inline asm: next to LDS-DMA the compiler would put
+                                // s_waitcnt vmcnt(0) in front of an LDS atomic and drain the prefetch pipeline on every hit.
+                                uint32_t pos;
+                                const uint32_t lds_addr =
+                                    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&lcnt[ql]);
+                                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(lds_addr), "v"(1u) : "memory");
+                                if (pos < p.capw) seg[pos] = make_uint2(__float_as_uint(v * p.inv_scale2), (uint32_t)(row_b + rib));
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+            }
+        };
+
+        auto advance = [&]() {
+            const bool last_k = ks == KS - 1;
+            const int it_done = it;
+            if (++ks == KS) { ks = 0; ++it; }
+            if (++ks2 == KS) { ks2 = 0; ++it2; }
+            slot_c = slot_c == RING_SLOTS - 1 ? 0 : slot_c + 1;
+            slot_p = slot_p == RING_SLOTS - 1 ? 0 : slot_p + 1;
+            if (last_k) epilogue(it_done);
+        };
+
+        // steps alternate between the two fragment register sets
+        int s = 0;
+        for (; s + 1 < total; s += 2) {
+            step(a0, s);
+            advance();
+            step(a1, s + 1);
+            advance();
+        }
+        if (s < total) {
+            step(a0, s);
+            advance();
+        }
+        // drain the never-consumed tail prefetches; naming all eight fragments keeps their registers reserved until here
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3])
+                     : "memory");
+    }
+
+    if constexpr (EPI == EPI_SETMAX) {
+        // set id = (stream*8 + wave)*8 + j*2 + half ; layout setmax[query][set]
+#pragma unroll
+        for (int n = 0; n < NBN; ++n) {
+            float* dst = p.setmax + (int64_t)(qcol0 + n * 32) * p.n_sets + (int64_t)(stream * 8 + wave) * 8 + half;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j * 2] = runmax[n][j];
+        }
+    } else {
+        __syncthreads();
+        for (int i = threadIdx.x; i < BN; i += 512) p.cntw[(int64_t)(qt * BN + i) * n_streams + stream] = lcnt[i];
+    }
+}
+
+// K3a. tau[q] = (k-th largest of the query's set maxima) - 2E, in accumulator units; -inf if fewer than k
+// non-empty sets exist (then every allowed row is emitted). One block per query (padding queries: +inf).
+// Only the first n_sets_used sets (streams that scanned at least one tile) are looked at.
+__global__ __launch_bounds__(256) void k_tau(const float* __restrict__ setmax, int n_sets, int n_sets_used, int k,
+                                             float two_e_scaled, int nq, float* __restrict__ tau) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t bc[4];
+    const int q = blockIdx.x;
+    if (q >= nq) {   // padding query (zero vector): must never emit
+        if (threadIdx.x == 0) tau[q] = INFINITY;
+        return;
+    }
+    const float* sm = setmax + (int64_t)q * n_sets;
+    if (k > n_sets_used) {
+        if (threadIdx.x == 0) tau[q] = -INFINITY;
+        return;
+    }
+    int64_t n_gt;
+    const uint32_t key = block_kth_largest([&](int64_t i) { return f2key(sm[i]); }, n_sets_used, k, hist, bc, &n_gt);
+    if (threadIdx.x == 0) {
+        const float v = key2f(key);
+        tau[q] = v > -INFINITY ? v - two_e_scaled : -INFINITY;
+    }
+}
+
+}  // namespace rdx

@@ -133,7 +133,7 @@ def test_all_rows_identical_ties(eng, oracle):
 def test_candidate_overflow_falls_back(eng, oracle):
     corpus = synth.make_corpus(20000, 1024)
     q = synth.make_queries(64, 1024, corpus)
-    ix = _index(eng, corpus, force_fast=1, cand_cap=64)     # 64 slots cannot hold the ~100+ hits of k=50
+    ix = _index(eng, corpus, force_fast=1, cand_cap=1)      # one slot per (query, stream) segment cannot hold k=50's hits
     st = _check(oracle, ix, corpus, q, 50, expect_path=0)
     assert st["exact_queries"] > 0
 
