@@ -442,8 +442,8 @@ extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim,
 // ------------------------------------------------------------------------------------------------
 template <int BN, int EPI, bool RES>
 static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t st) {
-    // LDS: query-image ring (or the whole resident query tile) + BN hit counters
-    const size_t lds = (size_t)(RES ? p.ksteps : RING_SLOTS) * BN * BK * 2 + BN * 4;
+    // LDS: query-image ring (or the whole resident query tile) + BN hit counters + BN thresholds
+    const size_t lds = (size_t)(RES ? p.ksteps : RING_SLOTS) * BN * BK * 2 + BN * 8;
     void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES> : k_scan<BN, EPI, false, RES>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
@@ -530,7 +530,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         const int64_t n_tiles = (h->rows + 255) / 256;
         if (n_tiles * h->ksteps >= ((int64_t)1 << 31)) return fail(RDX_ERR_STATE, "shard too large for one scan launch");
         // the 64-query tile stays resident in LDS when all its k-step images fit (no DMA, no barrier in the main loop)
-        const bool res = bn == 64 && (size_t)h->ksteps * 8192 + 256 <= 160 * 1024 - 1024;
+        const bool res = bn == 64 && (size_t)h->ksteps * 8192 + 512 <= 160 * 1024 - 1024;
         // bootstrap sample: every div-th tile. More rows sampled = tighter tau = fewer hits; keep the expected hits
         // per query (~1.3 k rows/sample_rows) around 4000/... of the refine list and the sample >= max(64k, 8192) rows
         const int64_t want_rows = std::max<int64_t>(64 * (int64_t)k, 8192);

@@ -37,8 +37,8 @@ namespace rdx {
 
 constexpr int EPI_SETMAX = 0;
 constexpr int EPI_EMIT = 1;
-constexpr int SETS_PER_STREAM = 64;   // bootstrap sets per (stream, query): 8 waves x 2 lane halves x 4 register classes
-constexpr int RING_SLOTS = 3;
+constexpr int SETS_PER_STREAM = 32;   // bootstrap sets per (stream, query): 8 waves x 2 lane halves x 2 register classes
+constexpr int RING_SLOTS = 4;     // LDS ring of query images: step s, s+1 (certified), s+2, s+3 (in flight)
 
 struct ScanParams {
     const _Float16* shadow;    // fragment-ordered corpus scan copy
@@ -134,19 +134,16 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
     // per-lane epilogue state
-    float runmax[EPI == EPI_SETMAX ? NBN : 1][4];
-    float tau_l[EPI == EPI_EMIT ? NBN : 1];
+    float runmax[EPI == EPI_SETMAX ? NBN : 1][2];
+    float* tau_s = reinterpret_cast<float*>(lcnt + BN);   // [BN] thresholds of this query tile (LDS: registers are scarce)
     const int qcol0 = qt * BN + l31;   // query of n-block 0; n-block n is +32 n
     if constexpr (EPI == EPI_SETMAX) {
 #pragma unroll
         for (int n = 0; n < NBN; ++n)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) runmax[n][j] = -INFINITY;
+            for (int j = 0; j < 2; ++j) runmax[n][j] = -INFINITY;
     } else {
-#pragma unroll
-        for (int n = 0; n < NBN; ++n) tau_l[n] = p.tau[qcol0 + n * 32];
-#pragma unroll
-        for (int n = 0; n < NBN; ++n) asm volatile("" : "+v"(tau_l[n]));   // compiler-visible loads are complete before the hand-counted vmcnt region
+        for (int i = threadIdx.x; i < BN; i += 512) tau_s[i] = p.tau[qt * BN + i];   // visible after the prologue barrier
     }
 
     // LDS address of this lane's query fragment for k sub-step kk (n-block n adds n*4096): row l31, chunk 2kk+half, swizzled
@@ -157,13 +154,12 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 
     if (total > 0) {
         half8 a0[4], a1[4];   // corpus fragments of the even / odd k-steps in flight
-        // ---- prologue: steps 0 and 1 in flight (order matters for the counted waits: B(0) A(0) B(1) A(1)) ----
+        // ---- prologue: query images of steps 0..2 (ring) or the whole tile (resident), corpus fragments of steps 0 and 1 ----
         if constexpr (RES) {
             for (int ks_i = 0; ks_i < KS; ++ks_i) issue_b(ks_i, ks_i);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
         } else {
-            issue_b(0, 0);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) issue_b(j % KS, j);   // step j reads k-step image j mod KS (one query tile for all corpus tiles)
         }
         {
             const char* s0 = a_src(0, 0);
@@ -178,50 +174,71 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         // (it would reuse the register and the late write-back would corrupt it): both fragment sets are kept alive
         // until the final s_waitcnt vmcnt(0) below.
         const bool have1 = total > 1;
-        if constexpr (!RES) issue_b(have1 ? ks1 : 0, 1);
         {
             const char* s1 = a_src(have1 ? it1 : 0, have1 ? ks1 : 0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) gload16(a1[kk], s1 + kk * 1024);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // the only barrier that waits for memory: every wave's prologue DMA has landed
 
         int it = 0, ks = 0;            // step being computed
-        int it2 = it1, ks2 = ks1 + 1;  // step s+2 (prefetched during step s)
+        int it2 = it1, ks2 = ks1 + 1;  // step s+2 (corpus fragments prefetched during step s)
         if (ks2 >= KS) { ks2 -= KS; ++it2; }
-        int slot_c = 0, slot_p = 2;    // ring slot of step s / of step s+2
+        int slot_c = 0;                // ring slot of step s (= s mod 4)
+        int ksb = 3 % KS;              // k-step image that step s+3 reads (issued during step s)
+
+        // The step's 4*NBN MFMAs run as NG groups of GB query blocks. The query fragments of group g+PD are read from LDS
+        // right behind the first MFMA of group g into a 4-deep register ring — also ACROSS the step boundary (the last PD
+        // groups of step s prefetch the first PD groups of step s+1), so the matrix pipe never drains between steps.
+        // Issue order pinned with sched_barrier(0).
+        constexpr int GB = 2;                        // query blocks (= MFMAs) per group
+        constexpr int GPK = NBN / GB;                // groups per k sub-step
+        constexpr int NG = 4 * GPK;                  // groups per step (4, 8 or 16: a multiple of the register ring)
+        constexpr int PD = NBN >= 8 ? 2 : (NG / 2 < 3 ? NG / 2 : 3);   // groups read ahead (BN = 256 has no registers for a third)
+        constexpr int NBUF = 4;
+        half8 bf[NBUF][GB];
+        auto load_group = [&](const char* img, int g, half8 (&dst)[GB]) {
+            const int kk = g / GPK, nb0 = (g % GPK) * GB;
+#pragma unroll
+            for (int j = 0; j < GB; ++j) dst[j] = *reinterpret_cast<const half8*>(img + b_off[kk] + (nb0 + j) * 4096);
+        };
+#pragma unroll
+        for (int g = 0; g < PD; ++g) load_group(smem, g, bf[g]);   // step 0 reads slot 0 / k-step image 0
 
         auto step = [&](half8 (&af)[4], int s) {
-            // (1) everything issued before the previous step has landed: this step's corpus fragments (mine) and my pieces
-            //     of its query image; the V operations of the previous step stay in flight
+            // my corpus fragments of this step have landed (issued two steps ago); the V operations of the previous step
+            // stay in flight. No barrier here: the query image of step s was certified by the mid-step barrier of step s-1.
             wait_vmcnt_keep<V>(af);
-            if constexpr (!RES) __builtin_amdgcn_s_barrier();   // ... for every wave; also: all waves are done with step s-1
+            const int ksn = ks + 1 == KS ? 0 : ks + 1;
             const char* st = smem + (RES ? ks : slot_c) * B_BYTES;
+            const char* stn = smem + (RES ? ksn : ((slot_c + 1) & 3)) * B_BYTES;   // image of step s+1
             const bool more = s + 2 < total;   // step s+2 exists; otherwise re-read this stream's first step (never used)
-            const int pks = more ? ks2 : 0;
-            const char* an = a_src(more ? it2 : 0, pks);
-            // The step's 4*NBN MFMAs run as groups of GB query blocks; the query fragments of group g+1 are read from LDS
-            // right behind the first MFMA of group g (register double buffer of GB fragments: their latency hides under
-            // the remaining MFMAs of the group). Issue order pinned with sched_barrier(0).
-            constexpr int GB = NBN < 4 ? NBN : 4;
-            constexpr int GPK = NBN / GB;          // groups per k sub-step
-            constexpr int NG = 4 * GPK;            // groups per step
-            half8 bf[2][GB];
-            auto load_group = [&](int g, half8 (&dst)[GB]) {
-                const int kk = g / GPK, nb0 = (g % GPK) * GB;
-#pragma unroll
-                for (int j = 0; j < GB; ++j) dst[j] = *reinterpret_cast<const half8*>(st + b_off[kk] + (nb0 + j) * 4096);
-            };
-            load_group(0, bf[0]);
+            const char* an = a_src(more ? it2 : 0, more ? ks2 : 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int kk = g / GPK, nb0 = (g % GPK) * GB;
+                if constexpr (!RES) {
+                    if (g == NG / 2) {
+                        // Mid-step: ONE barrier per step, and it never waits for memory in steady state. My DMA pieces of
+                        // image s+1 were issued two steps ago: 4 + V newer operations may stay in flight (A2 A3 of step s-2,
+                        // the V of step s-1, A0 A1 of this step). After the barrier every wave's pieces of image s+1 have
+                        // landed and every wave has left step s-1, whose ring slot is refilled with image s+3.
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + V) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        issue_b(ksb, (slot_c + 3) & 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < GB; ++j) {
-                    acc[nb0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[g & 1][j], acc[nb0 + j], 0, 0, 0);
-                    if (j == 0 && g + 1 < NG) {
+                    acc[nb0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[g % NBUF][j], acc[nb0 + j], 0, 0, 0);
+                    if (j == 0) {
                         __builtin_amdgcn_sched_barrier(0);
-                        load_group(g + 1, bf[(g + 1) & 1]);
+                        if (g + PD < NG) load_group(st, g + PD, bf[(g + PD) % NBUF]);
+                        else load_group(stn, g + PD - NG, bf[(g + PD) % NBUF]);   // first groups of step s+1 (after the mid barrier)
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -229,9 +246,6 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     __builtin_amdgcn_sched_barrier(0);
                     // the matrix pipe has read af[kk]: refill it with the fragment of step s+2 (lands during the next step)
                     gload16(af[kk], an + kk * 1024);
-                    if constexpr (!RES) {
-                        if (kk == 0) issue_b(pks, slot_p);   // query image of step s+2 into the slot step s-1 just released
-                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -257,20 +271,21 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     for (int r = 0; r < 16; ++r) {
                         float v = acc[n][r];
                         if (filt && !((okbits >> acc_row(r, half)) & 1u)) v = -INFINITY;
-                        runmax[n][r & 3] = fmaxf(runmax[n][r & 3], v);
+                        runmax[n][r & 1] = fmaxf(runmax[n][r & 1], v);
                     }
                 } else {
                     float mx = acc[n][0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[n][r]);
-                    if (__any(mx >= tau_l[n])) {
-                        const int ql = n * 32 + l31;
+                    const int ql = n * 32 + l31;
+                    const float tq = tau_s[ql];
+                    if (__any(mx >= tq)) {
                         uint2* seg = p.cand + ((int64_t)(qt * BN + ql) * n_streams + stream) * p.capw;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float v = acc[n][r];
                             const int rib = acc_row(r, half);
-                            if (v >= tau_l[n] && (!filt || ((okbits >> rib) & 1u))) {
+                            if (v >= tq && (!filt || ((okbits >> rib) & 1u))) {
                                 // LDS counter: no global round trip. Inline asm: next to LDS-DMA the compiler would put
                                 // s_waitcnt vmcnt(0) in front of an LDS atomic and drain the prefetch pipeline on every hit.
                                 uint32_t pos;
@@ -292,8 +307,8 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
             const int it_done = it;
             if (++ks == KS) { ks = 0; ++it; }
             if (++ks2 == KS) { ks2 = 0; ++it2; }
-            slot_c = slot_c == RING_SLOTS - 1 ? 0 : slot_c + 1;
-            slot_p = slot_p == RING_SLOTS - 1 ? 0 : slot_p + 1;
+            slot_c = (slot_c + 1) & 3;
+            if (++ksb == KS) ksb = 0;
             if (last_k) epilogue(it_done);
         };
 
@@ -315,12 +330,12 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     }
 
     if constexpr (EPI == EPI_SETMAX) {
-        // set id = (stream*8 + wave)*8 + j*2 + half ; layout setmax[query][set]
+        // set id = (stream*8 + wave)*4 + j*2 + half ; layout setmax[query][set]
 #pragma unroll
         for (int n = 0; n < NBN; ++n) {
-            float* dst = p.setmax + (int64_t)(qcol0 + n * 32) * p.n_sets + (int64_t)(stream * 8 + wave) * 8 + half;
+            float* dst = p.setmax + (int64_t)(qcol0 + n * 32) * p.n_sets + (int64_t)(stream * 8 + wave) * 4 + half;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j * 2] = runmax[n][j];
+            for (int j = 0; j < 2; ++j) dst[j * 2] = runmax[n][j];
         }
     } else {
         __syncthreads();
