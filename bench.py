@@ -214,6 +214,29 @@ def main():
                          "launch_rows": n_local, "launch_queries": B,
                          "hbm_frac_of_8TBs": round(bytes_ / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                          "mfma_frac_of_2.5PF": round(flops / (launch_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)})
+        # the same corpus swept with a small batch: the HBM-bound regime of the same kernel (BASELINE.json's
+        # ">= 50 % of the HBM roofline on the 10M x 1024 scan" is about THIS regime; at B = 1024 the scan is MFMA-bound)
+        small = None
+        if world == 1 and stats and stats["path"] == 0:
+            try:
+                bs = 64
+                qs = synth.torch_queries(bs, dim, device)
+                for _ in range(2):
+                    searcher.search(qs, k)
+                torch.cuda.synchronize(device)
+                ms_s, n_s, t0s = 0.0, 10, time.perf_counter()
+                for _ in range(n_s):
+                    searcher.search(qs, k)
+                    ms_s += shard.index.last_stats()["ms_scan_main"]
+                torch.cuda.synchronize(device)
+                wall = (time.perf_counter() - t0s) / n_s
+                by = n_local * dim_pad * 2.0 + bs * dim_pad * 2.0
+                gbs = by / (ms_s / n_s * 1e-3) / 1e9
+                small = {"batch": bs, "k": k, "queries_per_s": round(bs / wall, 1), "avg_launch_ms": round(ms_s / n_s, 4),
+                         "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 4)}
+            except Exception as e:
+                log(f"small-batch leg failed: {e!r}")
         cpu, rec = None, None
         if world == 1 and not args.no_cpu:
             try:
@@ -227,7 +250,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "rows_total": rows, "rows_per_gpu": n_local, "dim": dim,
                        "batch": B, "k": k, "corpus_dtype": wl["corpus"], "parallelism": f"row-shard x{world} + all-gather merge"},
-            "roofline": roof, "cpu_baseline": cpu, "recall_at_10": rec,
+            "roofline": roof, "roofline_small_batch": small, "cpu_baseline": cpu, "recall_at_10": rec,
             "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4), "exact_fallback_queries": stats["exact_queries"],
                            "emitted_per_query": round(stats["emitted"] / max(1, B), 1),
                            "rescored_per_query": round(stats["rescored"] / max(1, B), 2), "sample_rows": stats["sample_rows"],
