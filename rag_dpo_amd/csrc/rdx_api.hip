@@ -89,7 +89,7 @@ struct rdx_index {
 
     // options
     int force_exact = 0, force_fast = 0, profile = 0;
-    int sample_div = 32;
+    int sample_div = 64;
     int64_t cand_cap = 0;   // 0 = automatic
     int64_t row_base = 0;   // added to every returned row id (global ids of a shard)
 
@@ -578,10 +578,13 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, res, p, grid, st));
         mark(4);
         {
-            const size_t lds = (size_t)REFINE_LIST * 8;
+            // LDS list of the gathered hits: 4x the expected count (occupancy of the refine kernel), at most REFINE_LIST
+            uint32_t list_cap = 1024;
+            while (list_cap < (uint32_t)REFINE_LIST && list_cap < 4.0 * exp_hits * n_streams) list_cap *= 2;
+            const size_t lds = (size_t)list_cap * 8;
             HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(256), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
-                               k, h->two_e(), h->qhat.as<float>(), h->master, h->dim, h->row_base, d_score, d_row, d_count,
+                               list_cap, k, h->two_e(), h->qhat.as<float>(), h->master, h->dim, h->row_base, d_score, d_row, d_count,
                                h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
             HIP_TRY(hipGetLastError());
         }

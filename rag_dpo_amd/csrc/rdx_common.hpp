@@ -77,15 +77,32 @@ __device__ uint32_t block_kth_largest(KeyAt key_at, int64_t n, int64_t k, uint32
             if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t acc = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if ((int64_t)acc + hist[b] >= remaining) break;
-                acc += hist[b];
+        // bin where the count taken from the top reaches `remaining`: wave 0, lane l owns bins 4l..4l+3, suffix sums by
+        // shuffles, crossing lane by ballot (the counts are < 2^32 here; remaining <= n)
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            uint64_t suf = (uint64_t)h0 + h1 + h2 + h3;   // becomes sum over bins >= 4l
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint64_t v = __shfl_down(suf, off, 64);
+                if (l + off < 64) suf += v;
             }
-            bc[0] = (uint32_t)b;
-            bc[1] = acc;
+            const unsigned long long m = __ballot(suf >= (uint64_t)remaining);   // never empty: suf(lane 0) = n' >= remaining
+            const int L = 63 - __clzll(m);
+            if (l == L) {
+                uint32_t acc = (uint32_t)(suf - ((uint64_t)h0 + h1 + h2 + h3));   // count in bins above this lane's
+                int b = 4 * l + 3;
+                const uint32_t hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                for (int j = 3; j > 0; --j) {
+                    if ((uint64_t)acc + hh[j] >= (uint64_t)remaining) break;
+                    acc += hh[j];
+                    --b;
+                }
+                bc[0] = (uint32_t)b;
+                bc[1] = acc;
+            }
         }
         __syncthreads();
         prefix |= bc[0] << shift;

@@ -24,7 +24,7 @@ struct RefineCounters {   // one per index, zeroed before every search
 //   sum, oracle/rdx_oracle.c) and ranked (score desc, row asc).
 //   A segment, list or P overflow cannot be answered here: the query is flagged for the exact full scan.
 __global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
-                                                int n_streams, uint32_t capw, int k, float two_e,
+                                                int n_streams, uint32_t capw, uint32_t list_cap, int k, float two_e,
                                                 const float* __restrict__ qhat, const float* __restrict__ master, int dim,
                                                 int64_t row_base, float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                 int32_t* __restrict__ out_count, int32_t* __restrict__ exact_list,
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, 
     __syncthreads();
     const uint32_t m = seg_off[n_streams];
     if (threadIdx.x == 0) atomicAdd(&ctr->emitted, (unsigned long long)m);
-    if (overflow || m > REFINE_LIST) {
+    if (overflow || m > list_cap) {
         if (threadIdx.x == 0) exact_list[atomicAdd(&ctr->n_exact, 1)] = q;
         return;
     }
