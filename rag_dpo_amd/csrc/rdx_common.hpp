@@ -21,6 +21,15 @@ namespace rdx {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef RDX_MFMA16
+// 1 (default): the scan uses v_mfma_f32_16x16x32_f16; 0: v_mfma_f32_32x32x16_f16. Same cycles per flop, but the chip
+// holds a higher clock on the 16x16x32 shape under this load (MI355X_MICROARCH.md "DVFS give-back" item 7): measured
+// +8 % on the B = 1024 scan (tools/ab_m16.py, same box, interleaved runs). The two shapes want different fragment
+// orders of the corpus scan copy, so the switch is compile-time.
+#define RDX_MFMA16 1
+#endif
 
 constexpr int TILE_ROWS = 256;                    // corpus rows per scan tile / shadow block
 constexpr int BK = 64;                            // k elements per k-step image
@@ -30,6 +39,15 @@ constexpr int SETS_PER_WAVE = 32;                 // threshold-bootstrap sets pe
 
 // offset (in halfs) of element (row r, column k) inside the fragment-ordered corpus scan copy
 __host__ __device__ inline int64_t corpus_off(int64_t r, int k, int ksteps) {
+#if RDX_MFMA16
+    // 16x16x32 A operand: chunk (rb, c = k/32, m = row half): lane l = row m*16 + (l & 15), k = c*32 + 8*(l >> 4) + 0..7
+    {
+        const int64_t rb16 = r >> 5;
+        const int m = (int)((r >> 4) & 1), c = k >> 5;
+        const int lane16 = (int)(r & 15) + (((k & 31) >> 3) << 4);
+        return (((rb16 * (ksteps * 2) + c) * 2 + m) * 64 + lane16) * 8 + (k & 7);
+    }
+#endif
     const int64_t rb = r >> 5;
     const int kc = k >> 4;
     const int lane = (int)(r & 31) + (((k & 15) >> 3) << 5);

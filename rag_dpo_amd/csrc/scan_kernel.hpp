@@ -127,6 +127,20 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096 + lane * 16;
     };
 
+#if RDX_MFMA16
+    // v_mfma_f32_16x16x32_f16: the wave's 32 rows are two 16-row blocks m, the queries NB16 blocks of 16; C layout
+    // col = lane & 15 (query), row = (lane >> 4) * 4 + reg
+    constexpr int NB16 = BN / 16;
+    const int l15 = lane & 15, lq = lane >> 4;
+    f32x4 acc[2][NB16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NB16; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
+    float runmax[EPI == EPI_SETMAX ? NB16 : 1][1];
+#else
     f32x16 acc[NBN];
 #pragma unroll
     for (int n = 0; n < NBN; ++n)
@@ -135,22 +149,31 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 
     // per-lane epilogue state
     float runmax[EPI == EPI_SETMAX ? NBN : 1][2];
+#endif
     float* tau_s = reinterpret_cast<float*>(lcnt + BN);   // [BN] thresholds of this query tile (LDS: registers are scarce)
     const int qcol0 = qt * BN + l31;   // query of n-block 0; n-block n is +32 n
     if constexpr (EPI == EPI_SETMAX) {
 #pragma unroll
-        for (int n = 0; n < NBN; ++n)
+        for (int n = 0; n < (int)(sizeof(runmax) / sizeof(runmax[0])); ++n)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) runmax[n][j] = -INFINITY;
+            for (int j = 0; j < (int)(sizeof(runmax[0]) / sizeof(float)); ++j) runmax[n][j] = -INFINITY;
     } else {
         for (int i = threadIdx.x; i < BN; i += 512) tau_s[i] = p.tau[qt * BN + i];   // visible after the prologue barrier
     }
 
     // LDS address of this lane's query fragment for k sub-step kk (n-block n adds n*4096): row l31, chunk 2kk+half, swizzled
+#if RDX_MFMA16
+    // 16x16x32: row l15 of the 16-query block, 16-B chunk 4*kk32 + lq of the 64-k image row
+    const int b_sw = ((((qt * BN) % 256) + l15) >> 1) & 7;
+    int b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_off[kk] = l15 * 128 + (((kk * 4 + lq) ^ b_sw) << 4);
+#else
     const int b_sw = ((((qt * BN) % 256) + l31) >> 1) & 7;   // identical for every n-block (32 rows = 4 swizzle periods)
     int b_off[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) b_off[kk] = l31 * 128 + (((kk * 2 + half) ^ b_sw) << 4);
+#endif
 
     if (total > 0) {
         half8 a0[4], a1[4];   // corpus fragments of the even / odd k-steps in flight
@@ -192,16 +215,24 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         // right behind the first MFMA of group g into a 4-deep register ring — also ACROSS the step boundary (the last PD
         // groups of step s prefetch the first PD groups of step s+1), so the matrix pipe never drains between steps.
         // Issue order pinned with sched_barrier(0).
-        constexpr int GB = 2;                        // query blocks (= MFMAs) per group
+        constexpr int GB = 2;                        // query blocks per group
+#if RDX_MFMA16
+        constexpr int NKK = 2;                       // k sub-steps of 32
+        constexpr int GPK = (BN / 16) / GB;          // groups per k sub-step
+        constexpr int QB_BYTES = 2048;               // LDS bytes of one 16-query block
+#else
+        constexpr int NKK = 4;                       // k sub-steps of 16
         constexpr int GPK = NBN / GB;                // groups per k sub-step
-        constexpr int NG = 4 * GPK;                  // groups per step (4, 8 or 16: a multiple of the register ring)
-        constexpr int PD = NBN >= 8 ? 2 : (NG / 2 < 3 ? NG / 2 : 3);   // groups read ahead (BN = 256 has no registers for a third)
+        constexpr int QB_BYTES = 4096;               // LDS bytes of one 32-query block
+#endif
+        constexpr int NG = NKK * GPK;                // groups per step (4, 8 or 16: a multiple of the register ring)
+        constexpr int PD = NBN >= 8 ? (RDX_MFMA16 ? 1 : 2) : (NG / 2 < 3 ? NG / 2 : 3);   // groups read ahead (BN = 256 has no registers for more)
         constexpr int NBUF = 4;
         half8 bf[NBUF][GB];
         auto load_group = [&](const char* img, int g, half8 (&dst)[GB]) {
             const int kk = g / GPK, nb0 = (g % GPK) * GB;
 #pragma unroll
-            for (int j = 0; j < GB; ++j) dst[j] = *reinterpret_cast<const half8*>(img + b_off[kk] + (nb0 + j) * 4096);
+            for (int j = 0; j < GB; ++j) dst[j] = *reinterpret_cast<const half8*>(img + b_off[kk] + (nb0 + j) * QB_BYTES);
         };
 #pragma unroll
         for (int g = 0; g < PD; ++g) load_group(smem, g, bf[g]);   // step 0 reads slot 0 / k-step image 0
@@ -234,18 +265,30 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                 }
 #pragma unroll
                 for (int j = 0; j < GB; ++j) {
+#if RDX_MFMA16
+                    acc[0][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk], bf[g % NBUF][j], acc[0][nb0 + j], 0, 0, 0);
+#else
                     acc[nb0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[g % NBUF][j], acc[nb0 + j], 0, 0, 0);
+#endif
                     if (j == 0) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (g + PD < NG) load_group(st, g + PD, bf[(g + PD) % NBUF]);
                         else load_group(stn, g + PD - NG, bf[(g + PD) % NBUF]);   // first groups of step s+1 (after the mid barrier)
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#if RDX_MFMA16
+                    acc[1][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk + 1], bf[g % NBUF][j], acc[1][nb0 + j], 0, 0, 0);
+#endif
                 }
                 if ((g % GPK) == GPK - 1) {
                     __builtin_amdgcn_sched_barrier(0);
-                    // the matrix pipe has read af[kk]: refill it with the fragment of step s+2 (lands during the next step)
+                    // the matrix pipe has read this sub-step's fragments: refill them with those of step s+2 (land during the next step)
+#if RDX_MFMA16
+                    gload16(af[2 * kk], an + (2 * kk) * 1024);
+                    gload16(af[2 * kk + 1], an + (2 * kk + 1) * 1024);
+#else
                     gload16(af[kk], an + kk * 1024);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -264,6 +307,48 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                 if (row_b < p.rows) okbits &= p.allow[row_b >> 5];
             }
             const bool filt = HAS_MASK || ragged;
+#if RDX_MFMA16
+#pragma unroll
+            for (int n = 0; n < NB16; ++n) {
+                if constexpr (EPI == EPI_SETMAX) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[m][n][r];
+                            if (filt && !((okbits >> (m * 16 + lq * 4 + r)) & 1u)) v = -INFINITY;
+                            runmax[n][0] = fmaxf(runmax[n][0], v);
+                        }
+                } else {
+                    float mx = fmaxf(acc[0][n][0], acc[1][n][0]);
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) mx = fmaxf(mx, fmaxf(acc[0][n][r], acc[1][n][r]));
+                    const int ql = n * 16 + l15;
+                    const float tq = tau_s[ql];
+                    if (__any(mx >= tq)) {
+                        uint2* seg = p.cand + ((int64_t)(qt * BN + ql) * n_streams + stream) * p.capw;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[m][n][r];
+                                const int rib = m * 16 + lq * 4 + r;
+                                if (v >= tq && (!filt || ((okbits >> rib) & 1u))) {
+                                    uint32_t pos;
+                                    const uint32_t lds_addr =
+                                        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&lcnt[ql]);
+                                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(lds_addr), "v"(1u) : "memory");
+                                    if (pos < p.capw) seg[pos] = make_uint2(__float_as_uint(v * p.inv_scale2), (uint32_t)(row_b + rib));
+                                }
+                            }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
+            }
+#else
 #pragma unroll
             for (int n = 0; n < NBN; ++n) {
                 if constexpr (EPI == EPI_SETMAX) {
@@ -300,6 +385,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
             }
+#endif
         };
 
         auto advance = [&]() {
@@ -330,6 +416,12 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     }
 
     if constexpr (EPI == EPI_SETMAX) {
+#if RDX_MFMA16
+        // set id = (stream*8 + wave)*4 + (lane >> 4) ; layout setmax[query][set]
+#pragma unroll
+        for (int n = 0; n < NB16; ++n)
+            p.setmax[(int64_t)(qt * BN + n * 16 + l15) * p.n_sets + (int64_t)(stream * 8 + wave) * 4 + lq] = runmax[n][0];
+#else
         // set id = (stream*8 + wave)*4 + j*2 + half ; layout setmax[query][set]
 #pragma unroll
         for (int n = 0; n < NBN; ++n) {
@@ -337,6 +429,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) dst[j * 2] = runmax[n][j];
         }
+#endif
     } else {
         __syncthreads();
         for (int i = threadIdx.x; i < BN; i += 512) p.cntw[(int64_t)(qt * BN + i) * n_streams + stream] = lcnt[i];
