@@ -3,11 +3,13 @@
 // HBM layout of one corpus shard (all owned by rdx_index, see rdx_api.hip):
 //   master  fp32 [cap_rows][dim]   row-major L2-normalised rows; the exact re-score and the exact scan read it
 //   shadow  fp16 "scan copy", value = master * 2^scale_log2, stored in MFMA FRAGMENT ORDER:
-//           [row block rb = row/32][k chunk kc = k/16][lane 0..63][8 halfs]
-//           lane l of chunk (rb, kc) holds row rb*32 + (l & 31), k = kc*16 + 8*(l >> 5) + 0..7 — exactly the A operand
-//           of v_mfma_f32_32x32x16_f16. One chunk = 1 KiB = one fully coalesced global_load_dwordx4 of a wavefront,
-//           and all chunks of a 32-row block are contiguous (dim_pad/16 KiB): a wave streams its rows straight from
-//           HBM into VGPRs, no LDS, no address arithmetic beyond "+1 KiB".
+//           [row block rb = row/32][k chunk c = k/32][row half m][lane 0..63][8 halfs]
+//           lane l of chunk (rb, c, m) holds row rb*32 + m*16 + (l & 15), k = c*32 + 8*(l >> 4) + 0..7 — exactly the A
+//           operand of v_mfma_f32_16x16x32_f16 (RDX_MFMA16 = 0 builds use the 32x32x16 order instead:
+//           [rb][k/16][lane], row rb*32 + (l & 31), k = 16*(k/16) + 8*(l >> 5) + 0..7).
+//           One chunk = 1 KiB = one fully coalesced global_load_dwordx4 of a wavefront, and all chunks of a 32-row block
+//           are contiguous (dim_pad/16 KiB): a wave streams its rows straight from HBM into VGPRs, no LDS, no address
+//           arithmetic beyond "+1 KiB".
 //   query scan copy (per search): [query block of 256][k-step ks = k/64][256 rows][64 k] fp16, i.e. one 32 KiB LDS image
 //           per (block, k-step). Inside an image row r (128 B = eight 16-B chunks) chunk c sits in slot c ^ ((r >> 1) & 7):
 //           the XOR makes the ds_read_b128 fragment reads of 16 different rows hit 16 different 16-B bank slots

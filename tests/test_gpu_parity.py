@@ -199,3 +199,81 @@ def test_merge_parity(eng, oracle):
     for b in range(B):
         np.testing.assert_array_equal(gr[b, :gc[b]], er[b, :ec[b]])
         np.testing.assert_array_equal(gs[b, :gc[b]], es[b, :ec[b]])
+
+
+@pytest.mark.parametrize("k", [256, 300])
+def test_large_k(eng, oracle, k):
+    """k = 256 is the largest the MFMA path serves, k = 300 goes through the exact full scan."""
+    corpus = synth.make_corpus(12000, 1024)
+    q = synth.make_queries(20, 1024, corpus)
+    ix = _index(eng, corpus, force_fast=1)
+    st = _check(oracle, ix, corpus, q, k)
+    assert st["path"] == (0 if k <= 256 else 1)
+
+
+def test_single_query_large_corpus_uses_scan(eng, oracle):
+    """the reference's production shape (B = 1, k = 50) on a corpus big enough for the streaming scan"""
+    corpus = synth.make_corpus(70000, 1024)
+    q = synth.make_queries(1, 1024, corpus)
+    ix = _index(eng, corpus)
+    _check(oracle, ix, corpus, q, 50, expect_path=0)
+
+
+def test_more_queries_than_one_launch(eng, oracle):
+    """nq > 4096 is cut into pipeline passes; results per query are independent of the batching"""
+    corpus = synth.make_corpus(5000, 256)
+    q = np.random.default_rng(4).standard_normal((4100, 256)).astype(np.float32)
+    ix = _index(eng, corpus, force_fast=1)
+    s, r, c = ix.search(q, 5)
+    s1, r1, c1 = ix.search(q[4090:4100], 5)
+    np.testing.assert_array_equal(r[4090:4100], r1)
+    np.testing.assert_array_equal(s[4090:4100], s1)
+    es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q[:64], 5)
+    np.testing.assert_array_equal(r[:64], er)
+    np.testing.assert_array_equal(s[:64], es)
+
+
+def test_concurrent_callers(eng, oracle):
+    """one index shared by several threads (the Streamlit cache_resource situation): calls serialise internally"""
+    import threading
+    corpus = synth.make_corpus(8000, 1024)
+    ix = _index(eng, corpus, force_fast=1)
+    ch = oracle.normalize_rows(corpus)
+    errs = []
+
+    def work(seed):
+        try:
+            q = np.random.default_rng(seed).standard_normal((30 + seed, 1024)).astype(np.float32)
+            for _ in range(3):
+                s, r, c = ix.search(q, 10)
+                es, er, ec = oracle.cosine_topk(ch, q, 10)
+                assert (r == er).all() and (s == es).all()
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+
+
+def test_device_pointer_path_matches_host_path(eng):
+    """RDX_DEVICE (torch CUDA tensors, current stream) and RDX_HOST (numpy) give the same bits"""
+    import torch
+    corpus = synth.make_corpus(9000, 1024)
+    q = synth.make_queries(100, 1024, corpus)
+    ix = eng.HipIndex(1024)
+    ix.add(torch.from_numpy(corpus).cuda())
+    ix.set_option("force_fast", 1)
+    s, r, c = ix.search(q, 10)
+    qd = torch.from_numpy(q).cuda()
+    sd = torch.empty((100, 10), dtype=torch.float32, device="cuda")
+    rd = torch.empty((100, 10), dtype=torch.int64, device="cuda")
+    cd = torch.empty((100,), dtype=torch.int32, device="cuda")
+    ix.search_device(qd, 10, sd, rd, cd)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rd.cpu().numpy(), r)
+    np.testing.assert_array_equal(sd.cpu().numpy(), s)
+    ix.set_option("row_base", 1000)
+    s2, r2, c2 = ix.search(q[:3], 10)
+    np.testing.assert_array_equal(r2, r[:3] + 1000)
