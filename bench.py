@@ -127,11 +127,18 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
+    ap.add_argument("--check-merged", action="store_true",
+                    help="N>1: rank 0 also builds the WHOLE corpus in one index and checks that the merged result is bit-identical")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank path on a ONE-GPU box: RDX_BENCH_REHEARSAL=1 puts every rank on cuda:0 and runs the
+    # collective over gloo through host memory. Never used by the driver; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("RDX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -140,7 +147,10 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
 
     wl = dict(WORKLOADS[args.workload])
     if args.rows:
@@ -156,7 +166,7 @@ def main():
     shard = HipShard(dim, local_rank, row_offset=lo)
     build_shard(shard, lo, hi, dim, wl["corpus"], device)
     log(f"[rank {rank}] shard rows [{lo}, {hi}) resident in {time.time() - t_build:.1f}s")
-    searcher = ShardedSearcher(shard)
+    searcher = ShardedSearcher(shard, host_staged=rehearsal)
     queries = synth.torch_queries(B, dim, device)
     shard.index.set_option("profile", 1)    # HIP events around every kernel, on the stream they run on
 
@@ -179,10 +189,22 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    merged_ok = None
+    if args.check_merged and world > 1:
+        ms_, mr_, mc_ = [t.clone() for t in searcher.search(queries, k)]   # identical on every rank by construction
+        if rank == 0:
+            from rag_dpo_amd.engine import HipIndex
+            whole = HipShard(dim, local_rank, row_offset=0)
+            build_shard(whole, 0, rows, dim, wl["corpus"], device)
+            ws = torch.empty_like(ms_); wr = torch.empty_like(mr_); wc = torch.empty_like(mc_)
+            whole.search(queries, k, ws, wr, wc)
+            torch.cuda.synchronize(device)
+            merged_ok = bool((wr == mr_).all() and (ws == ms_).all() and (wc == mc_).all())
+            whole.index.close()
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -251,6 +273,7 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}", "rows_total": rows, "rows_per_gpu": n_local, "dim": dim,
                        "batch": B, "k": k, "corpus_dtype": wl["corpus"], "parallelism": f"row-shard x{world} + all-gather merge"},
             "roofline": roof, "roofline_small_batch": small, "cpu_baseline": cpu, "recall_at_10": rec,
+            "merged_equals_single_index": merged_ok,
             "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4), "exact_fallback_queries": stats["exact_queries"],
                            "emitted_per_query": round(stats["emitted"] / max(1, B), 1),
                            "rescored_per_query": round(stats["rescored"] / max(1, B), 2), "sample_rows": stats["sample_rows"],

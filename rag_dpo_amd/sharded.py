@@ -59,9 +59,10 @@ class ShardedSearcher:
     """`shard` provides search(queries, k, out_score, out_row, out_count) answering with GLOBAL row ids and
     merge_packed(...) over the all-gather receive buffer."""
 
-    def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device=None):
+    def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device=None, host_staged: bool = False):
         self.shard = shard
         self.group = group
+        self.host_staged = host_staged
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = device if device is not None else getattr(shard, "device", torch.device("cpu"))
@@ -98,6 +99,14 @@ class ShardedSearcher:
         self.shard.search(queries, k, s, r, c)
         if self.world == 1:
             return s, r, c
-        dist.all_gather_into_tensor(allb, local, group=self.group)   # the ONE exchange step (RCCL over xGMI)
+        if self.host_staged:
+            # rehearsal only (several ranks sharing ONE GPU over gloo, which cannot move device memory): same packed
+            # layout, same merge kernel, the collective alone goes through host memory
+            h_local = local.cpu()
+            h_all = torch.empty(self.world * per_pad, dtype=torch.uint8)
+            dist.all_gather_into_tensor(h_all, h_local, group=self.group)
+            allb.copy_(h_all)
+        else:
+            dist.all_gather_into_tensor(allb, local, group=self.group)   # the ONE exchange step (RCCL over xGMI)
         self.shard.merge_packed(allb, per_pad, self.world, nq, k, out[0], out[1], out[2])
         return out
