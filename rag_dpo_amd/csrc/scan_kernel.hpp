@@ -31,9 +31,21 @@
 //   EPI_EMIT (main pass): every (row, query) whose coarse score >= tau[query] is appended to the (query, stream) candidate
 //     segment: slot from an LDS counter (no global atomics, no round trip), 8-byte fire-and-forget store.
 #pragma once
+#include <type_traits>
+
 #include "rdx_common.hpp"
 
 namespace rdx {
+
+#if defined(RDX_ABL_NOA) || defined(RDX_ABL_NOB) || defined(RDX_ABL_NOEMIT)
+#define RDX_EMIT_ON false   // ablation builds never emit (their scores are meaningless)
+#else
+#define RDX_EMIT_ON true
+#endif
+
+#ifndef RDX_SPREAD_DMA
+#define RDX_SPREAD_DMA 0
+#endif
 
 constexpr int EPI_SETMAX = 0;
 constexpr int EPI_EMIT = 1;
@@ -226,7 +238,11 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         constexpr int QB_BYTES = 4096;               // LDS bytes of one 32-query block
 #endif
         constexpr int NG = NKK * GPK;                // groups per step (4, 8 or 16: a multiple of the register ring)
-        constexpr int PD = NBN >= 8 ? (RDX_MFMA16 ? 1 : 2) : (NG / 2 < 3 ? NG / 2 : 3);   // groups read ahead (BN = 256 has no registers for more)
+#ifndef RDX_PD_EMIT
+#define RDX_PD_EMIT 1
+#endif
+        // groups read ahead; at BN = 256 the register file decides (the bootstrap kernel also carries its running maxima)
+        constexpr int PD = NBN >= 8 ? (RDX_MFMA16 ? (EPI == EPI_EMIT ? RDX_PD_EMIT : 1) : 2) : (NG / 2 < 3 ? NG / 2 : 3);
         constexpr int NBUF = 4;
         half8 bf[NBUF][GB];
         auto load_group = [&](const char* img, int g, half8 (&dst)[GB]) {
@@ -259,9 +275,26 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                         __builtin_amdgcn_sched_barrier(0);
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + V) : "memory");
                         __builtin_amdgcn_s_barrier();
+#if !defined(RDX_ABL_NOB) && !RDX_SPREAD_DMA
                         issue_b(ksb, (slot_c + 3) & 3);
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#if !defined(RDX_ABL_NOB) && RDX_SPREAD_DMA
+                    // the DMA pieces of image s+3 are spread over the second half of the step (one per DMA_EVERY groups)
+                    // instead of one burst behind the barrier: their issue cost then hides under the MFMAs of both waves
+                    constexpr int DMA_EVERY = (NG / 2) / NPB > 0 ? (NG / 2) / NPB : 1;
+                    if (g >= NG / 2 && (g - NG / 2) % DMA_EVERY == 0 && (g - NG / 2) / DMA_EVERY < NPB) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int i = (g - NG / 2) / DMA_EVERY;
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void*)(qbase + (int64_t)ksb * KSTEP_BYTES + i * 1024),
+                            (__attribute__((address_space(3))) void*)(smem + ((slot_c + 3) & 3) * B_BYTES + wave * (NPB * 1024) + i * 1024),
+                            16, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
                 }
 #pragma unroll
                 for (int j = 0; j < GB; ++j) {
@@ -283,7 +316,9 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                 if ((g % GPK) == GPK - 1) {
                     __builtin_amdgcn_sched_barrier(0);
                     // the matrix pipe has read this sub-step's fragments: refill them with those of step s+2 (land during the next step)
-#if RDX_MFMA16
+#if defined(RDX_ABL_NOA)   // developer ablation (tools/ab_lib.py): timing without the corpus stream, results are garbage
+                    asm volatile("" ::"v"(an));
+#elif RDX_MFMA16
                     gload16(af[2 * kk], an + (2 * kk) * 1024);
                     gload16(af[2 * kk + 1], an + (2 * kk + 1) * 1024);
 #else
@@ -323,9 +358,13 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     float mx = fmaxf(acc[0][n][0], acc[1][n][0]);
 #pragma unroll
                     for (int r = 1; r < 4; ++r) mx = fmaxf(mx, fmaxf(acc[0][n][r], acc[1][n][r]));
-                    const int ql = n * 16 + l15;
+                    int ql = n * 16 + l15;
+                    // opaque to the optimiser: otherwise the 16 per-block LDS addresses and segment pointers are hoisted out
+                    // of the tile loop as loop invariants and cost ~50 VGPRs the main loop needs
+                    asm volatile("" : "+v"(ql));
                     const float tq = tau_s[ql];
-                    if (__any(mx >= tq)) {
+                    if (!RDX_EMIT_ON) asm volatile("" ::"v"(mx));   // keep the MFMAs alive in ablation builds
+                    if (RDX_EMIT_ON && __any(mx >= tq)) {
                         uint2* seg = p.cand + ((int64_t)(qt * BN + ql) * n_streams + stream) * p.capw;
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
@@ -364,7 +403,8 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[n][r]);
                     const int ql = n * 32 + l31;
                     const float tq = tau_s[ql];
-                    if (__any(mx >= tq)) {
+                    if (!RDX_EMIT_ON) asm volatile("" ::"v"(mx));   // keep the MFMAs alive in ablation builds
+                    if (RDX_EMIT_ON && __any(mx >= tq)) {
                         uint2* seg = p.cand + ((int64_t)(qt * BN + ql) * n_streams + stream) * p.capw;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
