@@ -170,7 +170,12 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 #pragma unroll
             for (int j = 0; j < (int)(sizeof(runmax[0]) / sizeof(float)); ++j) runmax[n][j] = -INFINITY;
     } else {
+#if RDX_MFMA16
+        // stored [l15][n] so that one ds_read_b128 fetches the thresholds of four consecutive query blocks of a lane
+        for (int i = threadIdx.x; i < BN; i += 512) tau_s[(i & 15) * (BN / 16) + (i >> 4)] = p.tau[qt * BN + i];
+#else
         for (int i = threadIdx.x; i < BN; i += 512) tau_s[i] = p.tau[qt * BN + i];   // visible after the prologue barrier
+#endif
     }
 
     // LDS address of this lane's query fragment for k sub-step kk (n-block n adds n*4096): row l31, chunk 2kk+half, swizzled
@@ -343,8 +348,25 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
             }
             const bool filt = HAS_MASK || ragged;
 #if RDX_MFMA16
+            // thresholds of this lane's query column, four blocks per LDS read, fetched one quad ahead of their use
+            f32x4 tq4 = {0.f, 0.f, 0.f, 0.f}, tq4n = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_EMIT) {
+                int t0 = l15 * NB16;
+                asm volatile("" : "+v"(t0));   // not a loop invariant worth a register
+                tq4n = *reinterpret_cast<const f32x4*>(tau_s + t0);
+            }
 #pragma unroll
             for (int n = 0; n < NB16; ++n) {
+                if constexpr (EPI == EPI_EMIT) {
+                    if ((n & 3) == 0) {
+                        tq4 = tq4n;
+                        if (n + 4 < NB16) {
+                            int t1 = l15 * NB16 + n + 4;
+                            asm volatile("" : "+v"(t1));
+                            tq4n = *reinterpret_cast<const f32x4*>(tau_s + t1);
+                        }
+                    }
+                }
                 if constexpr (EPI == EPI_SETMAX) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     // opaque to the optimiser: otherwise the 16 per-block LDS addresses and segment pointers are hoisted out
                     // of the tile loop as loop invariants and cost ~50 VGPRs the main loop needs
                     asm volatile("" : "+v"(ql));
-                    const float tq = tau_s[ql];
+                    const float tq = tq4[n & 3];
                     if (!RDX_EMIT_ON) asm volatile("" ::"v"(mx));   // keep the MFMAs alive in ablation builds
                     if (RDX_EMIT_ON && __any(mx >= tq)) {
                         uint2* seg = p.cand + ((int64_t)(qt * BN + ql) * n_streams + stream) * p.capw;
