@@ -26,9 +26,21 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
                                                    int64_t n, int dim, const int64_t* __restrict__ dst_rows,
                                                    int64_t row0, float* __restrict__ master,
                                                    _Float16* __restrict__ shadow, int ksteps, float scale,
-                                                   int* __restrict__ bad) {
+                                                   int* __restrict__ bad, int64_t n_pad = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if constexpr (QUERY) {
+        // the query scan copy is rebuilt for every search: padding rows [n, n_pad) and padding columns [dim, 64*ksteps) are
+        // written as zeros here (no separate memset launch)
+        if (i >= n) {
+            if (i < n_pad && shadow)
+                for (int g = lane; g < ksteps * 16; g += 64) shadow_store4<true>(shadow, row0 + i, 4 * g, ksteps, scale, make_float4(0.f, 0.f, 0.f, 0.f));
+            return;
+        }
+        if (shadow)
+            for (int g = (dim >> 2) + lane; g < ksteps * 16; g += 64)
+                shadow_store4<true>(shadow, row0 + i, 4 * g, ksteps, scale, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
     if (i >= n) return;
     const int n4 = dim >> 2;
     auto load4 = [&](int g) -> float4 {

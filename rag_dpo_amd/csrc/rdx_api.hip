@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -445,7 +446,11 @@ static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t 
     // LDS: query-image ring (or the whole resident query tile) + BN hit counters + BN thresholds
     const size_t lds = (size_t)(RES ? p.ksteps : RING_SLOTS) * BN * BK * 2 + BN * 8;
     void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES> : k_scan<BN, EPI, false, RES>;
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static size_t lds_set[2] = {0, 0};   // per instantiation: raise the dynamic-LDS limit once per size (RES sizes vary with dim)
+    if (lds_set[p.allow ? 1 : 0] < lds) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[p.allow ? 1 : 0] = lds;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
     HIP_TRY(hipGetLastError());
     return RDX_OK;
@@ -489,16 +494,14 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     // K1 on the queries: qhat (fp32, exact re-score) + tiled fp16 copy (scan)
     RDX_TRY(h->qhat.ensure((size_t)nq_pad * h->dim * 4));
     RDX_TRY(h->qshadow.ensure((size_t)nq_pad * h->dim_pad * 2));
-    RDX_TRY(h->bad.ensure(sizeof(int)));
     RDX_TRY(h->ctr.ensure(sizeof(RefineCounters)));
     RDX_TRY(h->exact_list.ensure((size_t)nq_pad * 4));
+    int* d_bad = reinterpret_cast<int*>(h->ctr.as<char>() + offsetof(RefineCounters, bad));
     mark(0);
-    HIP_TRY(hipMemsetAsync(h->bad.p, 0, sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(h->ctr.p, 0, sizeof(RefineCounters), st));
-    if (nq != nq_pad || h->dim != h->dim_pad) HIP_TRY(hipMemsetAsync(h->qshadow.p, 0, (size_t)nq_pad * h->dim_pad * 2, st));
-    hipLaunchKernelGGL(k_normalize<true>, dim3((int)((nq + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
+    HIP_TRY(hipMemsetAsync(h->ctr.p, 0, sizeof(RefineCounters), st));   // the only memset of a search (counters + NaN flag)
+    hipLaunchKernelGGL(k_normalize<true>, dim3((int)((nq_pad + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
                        (const int64_t*)nullptr, (int64_t)0, h->qhat.as<float>(), h->qshadow.as<_Float16>(), h->ksteps, h->scale(),
-                       h->bad.as<int>());
+                       d_bad, (int64_t)nq_pad);
     HIP_TRY(hipGetLastError());
     mark(1);
 
@@ -518,6 +521,8 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         HIP_TRY(hipMemcpyAsync(h->iota.p, io.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st));
+        HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         n_exact = (int)nq;
     } else {
         const int bn = nq <= 64 ? 64 : (nq <= 128 ? 128 : 256);
@@ -582,7 +587,11 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             uint32_t list_cap = 1024;
             while (list_cap < (uint32_t)REFINE_LIST && list_cap < 4.0 * exp_hits * n_streams) list_cap *= 2;
             const size_t lds = (size_t)list_cap * 8;
-            HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            static size_t refine_lds = 0;
+            if (refine_lds < lds) {
+                HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                refine_lds = lds;
+            }
             hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(256), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
                                list_cap, k, h->two_e(), h->qhat.as<float>(), h->master, h->dim, h->row_base, d_score, d_row, d_count,
                                h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
@@ -597,10 +606,9 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         acc_stats->scan_main_launch_queries = nq;
     }
     mark(6);
-    int bad = 0;
-    HIP_TRY(hipMemcpyAsync(&bad, h->bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (bad) return fail(RDX_ERR_INVALID, "query embeddings contain NaN or Inf");
+    // one host synchronisation per search (the counter block read back after K4, above); it also carried the NaN flag
+    if (ctr.bad) return fail(RDX_ERR_INVALID, "query embeddings contain NaN or Inf");
+    if (prof) HIP_TRY(hipEventSynchronize(h->ev[6]));
 
     acc_stats->sample_rows += exact_only ? 0 : sample_rows;
     acc_stats->emitted += (int64_t)ctr.emitted;

@@ -13,7 +13,7 @@ struct RefineCounters {   // one per index, zeroed before every search
     unsigned long long emitted;
     unsigned long long rescored;
     int n_exact;          // queries handed to the exact full scan
-    int pad;
+    int bad;              // set by K1 when a query embedding holds NaN/Inf
 };
 
 // One block (256 threads) per query.
