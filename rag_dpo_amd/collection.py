@@ -72,6 +72,8 @@ class Collection:
         self._cols: Dict[str, W.Column] = {}
         self._lock = threading.RLock()
         self._client = _client
+        self._dir: Optional[str] = None        # set by PersistentClient: where the snapshot + journal live
+        self._replaying = False
 
     # ---- small helpers ----------------------------------------------------------------------
     @property
@@ -195,6 +197,9 @@ class Collection:
                 self._row_of[ids[i]] = row
                 self._alive[row] = True
                 self._set_meta(row, metadatas[i] if metadatas is not None else None, replace=False)
+            self._log({"op": "add", "ids": [ids[i] for i in fresh],
+                       "documents": None if documents is None else [documents[i] for i in fresh],
+                       "metadatas": None if metadatas is None else [metadatas[i] for i in fresh]}, sel)
 
     def update(self, ids, embeddings=None, metadatas=None, documents=None, **_ignored):
         """reference tag_all_chunks.py:215,224 (metadatas only). Metadata updates MERGE into the stored dict,
@@ -218,6 +223,12 @@ class Collection:
                     self._set_meta(row, metadatas[i], replace=False)
                 if documents is not None:
                     self._docs[row] = documents[i]
+            if hit:
+                idx = [i for i, _ in hit]
+                self._log({"op": "update", "ids": [ids[i] for i in idx],
+                           "documents": None if documents is None else [documents[i] for i in idx],
+                           "metadatas": None if metadatas is None else [metadatas[i] for i in idx]},
+                          None if emb is None else np.ascontiguousarray(emb[idx]))
 
     def upsert(self, ids, embeddings=None, metadatas=None, documents=None, **_ignored):
         if isinstance(ids, str):
@@ -250,6 +261,9 @@ class Collection:
                 rows = np.flatnonzero(m).tolist() if m is not None else list(range(self._rows))
             else:
                 raise ValueError("delete needs ids= or where=")
+            gone = [self._ids[r] for r in rows if self._alive[r]]
+            if gone:
+                self._log({"op": "delete", "ids": gone}, None)
             for r in rows:
                 if self._alive[r]:
                     self._alive[r] = False
@@ -358,15 +372,43 @@ class Collection:
                 self.name = name
             if metadata is not None:
                 self.metadata = dict(metadata)
+            if self._dir:
+                self._write_header(self._dir, self._snap_rows)
 
     # ---- persistence: own shard format ------------------------------------------
+    # <dir>/collection.json        name, metadata, dim, rows of the snapshot
+    # <dir>/embeddings.f32.npy     snapshot: normalised fp32 rows, in row order
+    # <dir>/records.jsonl          snapshot: one {"id", "document", "metadata"} per row
+    # <dir>/journal.jsonl + .f32   every add/update/delete since the snapshot, appended when the call returns (chromadb's
+    #                              PersistentClient is durable per call and the reference never calls persist():
+    #                              create_chromadb_index.py writes, app.py reads in another process). persist() folds
+    #                              the journal into a new snapshot.
+    _snap_rows = 0
+
+    def _write_header(self, path: str, rows: int):
+        os.makedirs(path, exist_ok=True)
+        tmp = os.path.join(path, "collection.json.tmp")
+        with open(tmp, "w", encoding="utf-8") as f:
+            json.dump({"name": self.name, "metadata": self.metadata, "dim": self._dim, "rows": rows, "format": 2}, f)
+        os.replace(tmp, os.path.join(path, "collection.json"))
+
+    def _log(self, rec: dict, emb: Optional[np.ndarray]):
+        if not self._dir or self._replaying:
+            return
+        rec["n_emb"] = 0 if emb is None else int(emb.shape[0])
+        rec["dim"] = None if emb is None else int(emb.shape[1])
+        if emb is not None:
+            with open(os.path.join(self._dir, "journal.f32"), "ab") as f:
+                f.write(np.ascontiguousarray(emb, dtype=np.float32).tobytes())
+        with open(os.path.join(self._dir, "journal.jsonl"), "a", encoding="utf-8") as f:   # the line commits the op
+            f.write(json.dumps(rec, ensure_ascii=False) + "\n")
+
     def _save(self, path: str):
         with self._lock:
             if self._n_dead:
                 self._compact()
             os.makedirs(path, exist_ok=True)
             n = self._rows
-            meta = {"name": self.name, "metadata": self.metadata, "dim": self._dim, "rows": n, "format": 1}
             if n:
                 emb = self._engine.get(np.arange(n, dtype=np.int64))   # normalised fp32 rows
                 np.save(os.path.join(path, "embeddings.f32.npy"), emb)
@@ -374,34 +416,65 @@ class Collection:
                 for r in range(n):
                     f.write(json.dumps({"id": self._ids[r], "document": self._docs[r], "metadata": self._meta_of(r)},
                                        ensure_ascii=False) + "\n")
-            with open(os.path.join(path, "collection.json"), "w", encoding="utf-8") as f:
-                json.dump(meta, f)
+            self._write_header(path, n)
+            self._snap_rows = n
+            for fn in ("journal.jsonl", "journal.f32"):
+                fp = os.path.join(path, fn)
+                if os.path.exists(fp):
+                    os.remove(fp)
 
     def _load(self, path: str):
         with open(os.path.join(path, "collection.json"), encoding="utf-8") as f:
             meta = json.load(f)
         self.metadata = meta.get("metadata") or {}
         n = int(meta.get("rows", 0))
-        if not n:
-            return
-        emb = np.load(os.path.join(path, "embeddings.f32.npy"), mmap_mode="r", allow_pickle=False)
-        ids, docs, metas = [], [], []
-        with open(os.path.join(path, "records.jsonl"), encoding="utf-8") as f:
-            for line in f:
-                rec = json.loads(line)
-                ids.append(rec["id"])
-                docs.append(rec.get("document"))
-                metas.append(rec.get("metadata"))
-        step = 65536
-        for a in range(0, n, step):
-            b = min(n, a + step)
-            self.add(ids=ids[a:b], embeddings=np.asarray(emb[a:b]), documents=docs[a:b], metadatas=metas[a:b])
+        self._snap_rows = n
+        self._replaying = True
+        try:
+            if n:
+                emb = np.load(os.path.join(path, "embeddings.f32.npy"), mmap_mode="r", allow_pickle=False)
+                ids, docs, metas = [], [], []
+                with open(os.path.join(path, "records.jsonl"), encoding="utf-8") as f:
+                    for line in f:
+                        rec = json.loads(line)
+                        ids.append(rec["id"])
+                        docs.append(rec.get("document"))
+                        metas.append(rec.get("metadata"))
+                step = 65536
+                for a in range(0, n, step):
+                    b = min(n, a + step)
+                    self.add(ids=ids[a:b], embeddings=np.asarray(emb[a:b]), documents=docs[a:b], metadatas=metas[a:b])
+            jp = os.path.join(path, "journal.jsonl")
+            if os.path.exists(jp):
+                fp = os.path.join(path, "journal.f32")
+                raw = np.memmap(fp, dtype=np.float32, mode="r") if os.path.exists(fp) and os.path.getsize(fp) else None
+                pos = 0
+                with open(jp, encoding="utf-8") as f:
+                    for line in f:
+                        try:
+                            rec = json.loads(line)
+                        except ValueError:      # torn last line of a killed writer: the op never committed
+                            break
+                        emb = None
+                        if rec.get("n_emb"):
+                            cnt = rec["n_emb"] * rec["dim"]
+                            emb = np.array(raw[pos: pos + cnt]).reshape(rec["n_emb"], rec["dim"])
+                            pos += cnt
+                        if rec["op"] == "add":
+                            self.add(ids=rec["ids"], embeddings=emb, documents=rec["documents"], metadatas=rec["metadatas"])
+                        elif rec["op"] == "update":
+                            self.update(ids=rec["ids"], embeddings=emb, documents=rec["documents"], metadatas=rec["metadatas"])
+                        elif rec["op"] == "delete":
+                            self.delete(ids=rec["ids"])
+        finally:
+            self._replaying = False
 
 
 class PersistentClient:
     """chromadb.PersistentClient look-alike (reference app.py:58-59, create_chromadb_index.py:70-130,
     eval/run_eval.py:712-715): `PersistentClient(path).get_collection("rag_dpo_chunks")`.
-    Collections are loaded into HBM on open and written back by persist()/close()."""
+    Collections are loaded into HBM on open; every add/update/delete is journalled when it returns, persist()/close()
+    fold the journal into a snapshot."""
 
     def __init__(self, path: Optional[str] = None, device: int = 0, engine_factory=None, settings=None, **_ignored):
         self.path = path
@@ -414,6 +487,7 @@ class PersistentClient:
                 if os.path.exists(os.path.join(d, "collection.json")):
                     c = Collection(name, device=device, engine_factory=engine_factory, _client=self)
                     c._load(d)
+                    c._dir = d
                     self._cols[name] = c
 
     def create_collection(self, name: str, metadata: Optional[dict] = None, get_or_create: bool = False, **_ignored):
@@ -423,6 +497,9 @@ class PersistentClient:
             raise ValueError(f"Collection {name} already exists")
         c = Collection(name, metadata=metadata, device=self._device, engine_factory=self._factory, _client=self)
         self._cols[name] = c
+        if self.path:
+            c._dir = os.path.join(self.path, name)
+            c._write_header(c._dir, 0)
         return c
 
     def get_collection(self, name: str, **_ignored) -> Collection:
@@ -442,7 +519,7 @@ class PersistentClient:
         if self.path:
             d = os.path.join(self.path, name)
             if os.path.isdir(d):
-                for fn in ("collection.json", "records.jsonl", "embeddings.f32.npy"):
+                for fn in ("collection.json", "records.jsonl", "embeddings.f32.npy", "journal.jsonl", "journal.f32"):
                     fp = os.path.join(d, fn)
                     if os.path.exists(fp):
                         os.remove(fp)
@@ -457,14 +534,19 @@ class PersistentClient:
     def _rename(self, old: str, new: str):
         if new in self._cols:
             raise ValueError(f"Collection {new} already exists")
-        self._cols[new] = self._cols.pop(old)
+        c = self._cols[new] = self._cols.pop(old)
+        if self.path and c._dir and os.path.isdir(c._dir):
+            nd = os.path.join(self.path, new)
+            os.rename(c._dir, nd)
+            c._dir = nd
 
     def persist(self):
         if not self.path:
             return
         os.makedirs(self.path, exist_ok=True)
         for name, c in self._cols.items():
-            c._save(os.path.join(self.path, name))
+            c._dir = os.path.join(self.path, name)
+            c._save(c._dir)
 
     def close(self):
         self.persist()

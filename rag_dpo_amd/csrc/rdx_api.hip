@@ -515,11 +515,14 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     int64_t sample_rows = 0;
     if (exact_only) {
         for (int i = 2; i <= 5; ++i) mark(i);
-        RDX_TRY(h->iota.ensure((size_t)nq_pad * 4));
-        std::vector<int32_t> io((size_t)nq);
-        for (int64_t i = 0; i < nq; ++i) io[(size_t)i] = (int32_t)i;
-        HIP_TRY(hipMemcpyAsync(h->iota.p, io.data(), (size_t)nq * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if ((size_t)nq_pad * 4 > h->iota.bytes) {   // identity query list, uploaded once (grow-only), not per search
+            RDX_TRY(h->iota.ensure((size_t)nq_pad * 4));
+            const size_t cnt = h->iota.bytes / 4;
+            std::vector<int32_t> io(cnt);
+            for (size_t i = 0; i < cnt; ++i) io[i] = (int32_t)i;
+            HIP_TRY(hipMemcpyAsync(h->iota.p, io.data(), cnt * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st));
         HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

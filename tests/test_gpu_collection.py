@@ -24,3 +24,10 @@ def test_persistent_client_gpu(tmp_path):
     col2 = PersistentClient(path=str(tmp_path / "db")).get_collection("rag_dpo_chunks")
     after = col2.query(query_embeddings=q, n_results=50, where={"source": "CNIL"})
     assert after["ids"] == before["ids"]
+
+
+def test_indexer_flow_gpu(tmp_path):
+    """ingest -> verify -> reopen -> update on the HIP engine leaves the records (and the verify answers) the reference
+    indexer left (tests/golden/indexer_golden.json)"""
+    from test_indexer_golden import run_reset_then_update
+    run_reset_then_update(tmp_path, None)
