@@ -40,8 +40,9 @@ WORKLOADS = {
     "c4": dict(rows=10_000_000, dim=1024, batch=1024, k=10, corpus="fp32",
                desc="synthetic 10M x 1024 fp32 row-sharded over the GPUs, batch=1024 queries, top-10, all-gather merge"),
     "c5": dict(rows=10_000_000, dim=1024, batch=1024, k=10, corpus="bf16",
-               desc="synthetic 10M x 1024 bf16 corpus row-sharded over the GPUs, batch=1024 queries, top-10 "
-                    "(query vectors given; BGE-M3 encode not included)"),
+               desc="synthetic 10M x 1024 bf16 corpus row-sharded over the GPUs, batch=1024 queries, top-10, each step "
+                    "encodes its 1024 query texts first (BGE-M3 architecture = XLM-R-large, random-init fp16, PyTorch-ROCm; "
+                    "--no-encode times the search alone)"),
 }
 PEAK_HBM_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/f16 MFMA ~2.5 PF
@@ -127,6 +128,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
+    ap.add_argument("--no-encode", action="store_true", help="c5: leave the BGE-M3 query encode out of the step")
     ap.add_argument("--check-merged", action="store_true",
                     help="N>1: rank 0 also builds the WHOLE corpus in one index and checks that the merged result is bit-identical")
     args = ap.parse_args()
@@ -175,13 +177,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # C5: every step first encodes its B query texts (every rank encodes the same texts with the same weights: the query
+    # batch is replicated) and hands the device tensor straight to the search
+    encode = args.workload == "c5" and not args.no_encode
+    provider, texts, enc_ev = None, None, []
+    if encode:
+        from rag_dpo_amd.embedding_provider import EmbeddingProvider
+        provider = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device=str(device), dtype=torch.float16,
+                                     batch_size=256).load()
+        texts = synth.query_texts(B)
+
+    def step():
+        if not encode:
+            return searcher.search(queries, k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        q = provider.embed_device(texts)
+        e1.record()
+        enc_ev.append((e0, e1))
+        return searcher.search(q, k)
+
     for _ in range(args.warmup):
-        searcher.search(queries, k)
+        step()
     barrier()
+    enc_ev.clear()
     scan_ms, tot_ms, stats = 0.0, 0.0, None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        searcher.search(queries, k)
+        step()
         st = shard.index.last_stats()   # host struct copy, no device work
         scan_ms += st["ms_scan_main"]
         tot_ms += st["ms_total"]
@@ -274,7 +297,9 @@ def main():
                        "batch": B, "k": k, "corpus_dtype": wl["corpus"], "parallelism": f"row-shard x{world} + all-gather merge"},
             "roofline": roof, "roofline_small_batch": small, "cpu_baseline": cpu, "recall_at_10": rec,
             "merged_equals_single_index": merged_ok,
-            "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4), "exact_fallback_queries": stats["exact_queries"],
+            "encode": ({"model": "XLM-R-large (BGE-M3 architecture), random-init fp16, hashing tokenizer", "texts_per_step": B,
+                        "avg_ms": round(sum(a.elapsed_time(b) for a, b in enc_ev) / max(1, len(enc_ev)), 3)} if encode else None),
+            "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4),"exact_fallback_queries": stats["exact_queries"],
                            "emitted_per_query": round(stats["emitted"] / max(1, B), 1),
                            "rescored_per_query": round(stats["rescored"] / max(1, B), 2), "sample_rows": stats["sample_rows"],
                            "ms": {n_: round(stats[n_], 4) for n_ in ("ms_normalize", "ms_scan_sample", "ms_tau", "ms_scan_main",

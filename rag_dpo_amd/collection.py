@@ -558,3 +558,24 @@ class PersistentClient:
 
 def Client(**kw):   # chromadb.Client(): in-memory
     return PersistentClient(path=None, **kw)
+
+
+def import_collection(src, client: PersistentClient, name: Optional[str] = None, page: int = 5000) -> Collection:
+    """One-shot import of an existing Chroma collection. `src` is anything Chroma-shaped, e.g.
+    `chromadb.PersistentClient(path="data/vectordb/chromadb").get_collection("rag_dpo_chunks")` on a machine that has
+    chromadb: it is paged through `get(limit=, offset=, include=[embeddings, documents, metadatas])` (the paging the
+    reference itself uses, bm25_index.py:211-215) and re-added here, insertion order kept. chromadb is not imported by
+    this package."""
+    name = name or getattr(src, "name", "rag_dpo_chunks")
+    meta = dict(getattr(src, "metadata", None) or {"hnsw:space": "cosine"})
+    dst = client.create_collection(name=name, metadata=meta)
+    total, off = src.count(), 0
+    while off < total:
+        g = src.get(limit=page, offset=off, include=["embeddings", "documents", "metadatas"])
+        if not g["ids"]:
+            break
+        dst.add(ids=g["ids"], embeddings=np.asarray(g["embeddings"], dtype=np.float32), documents=g.get("documents"),
+                metadatas=g.get("metadatas"))
+        off += len(g["ids"])
+    client.persist()
+    return dst

@@ -46,6 +46,12 @@ namespace rdx {
 #ifndef RDX_SPREAD_DMA
 #define RDX_SPREAD_DMA 0
 #endif
+#ifndef RDX_DMA_STAGGER
+#define RDX_DMA_STAGGER 4   // wave-number mask: waves with (wave & mask) != 0 issue their query-image DMA later in the step
+#endif
+#ifndef RDX_DMA_LATE_NUM
+#define RDX_DMA_LATE_NUM 2  // late position = NG/2 + NUM*NG/8
+#endif
 
 constexpr int EPI_SETMAX = 0;
 constexpr int EPI_EMIT = 1;
@@ -109,6 +115,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
+    const bool dma_late = (wave & RDX_DMA_STAGGER) != 0;
 
     const int n_sched = (int)((p.n_tiles + p.tile_stride - 1) / p.tile_stride);   // tiles in this launch
     const int my_tiles = stream < n_sched ? (n_sched - stream + n_streams - 1) / n_streams : 0;
@@ -281,10 +288,20 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + V) : "memory");
                         __builtin_amdgcn_s_barrier();
 #if !defined(RDX_ABL_NOB) && !RDX_SPREAD_DMA
-                        issue_b(ksb, (slot_c + 3) & 3);
+                        if (!RDX_DMA_STAGGER || !dma_late) issue_b(ksb, (slot_c + 3) & 3);
 #endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#if !defined(RDX_ABL_NOB) && !RDX_SPREAD_DMA && RDX_DMA_STAGGER
+                    // the two waves of a SIMD issue their DMA pieces a quarter step apart: while one of them sits in the
+                    // (expensive) DMA issue the other one keeps the matrix pipe fed. Same order of vector-memory operations
+                    // inside the step for every wave (A0 A1 | DMA | A2 A3), so the counted waits are unchanged.
+                    if (g == NG / 2 + RDX_DMA_LATE_NUM * NG / 8) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (dma_late) issue_b(ksb, (slot_c + 3) & 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
 #if !defined(RDX_ABL_NOB) && RDX_SPREAD_DMA
                     // the DMA pieces of image s+3 are spread over the second half of the step (one per DMA_EVERY groups)
                     // instead of one burst behind the barrier: their issue cost then hides under the MFMAs of both waves

@@ -164,6 +164,17 @@ class EmbeddingProvider:
             raw = self._encode_raw(truncated)
             return self._normalize(raw).tolist()
 
+    def embed_device(self, texts: List[str]) -> torch.Tensor:
+        """the same encode as embed(), left on the device: [T, dims] fp32 CLS embeddings, NOT yet normalised. For callers
+        that hand the batch straight to the device index (HipIndex.add / search_device run K1 on it anyway), which
+        skips embed()'s T x 1024 Python-float round trip."""
+        if not texts:
+            return torch.empty((0, self._dims), dtype=torch.float32, device=self.device)
+        with self._lock:
+            if self._model is None:
+                self.load()
+            return self._encode_raw([t[:TRUNCATE_CHARS] if len(t) > TRUNCATE_CHARS else t for t in texts])
+
     def _normalize(self, raw: torch.Tensor) -> np.ndarray:
         """K1 on the device (librdx); x / max(|x|, 1e-12), the arithmetic the index uses for corpus rows"""
         from . import _lib as L

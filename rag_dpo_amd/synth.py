@@ -57,3 +57,18 @@ def torch_queries(b: int, dim: int, device):
     g = torch.Generator(device=device)
     g.manual_seed(4321)
     return torch.randn((b, dim), generator=g, device=device, dtype=torch.float32)
+
+
+_WORDS = ("durée conservation données personnelles traitement registre sous-traitant responsable AIPD analyse impact consentement "
+          "cookies traceurs vidéosurveillance salariés transfert hors union européenne violation notification CNIL délégué "
+          "protection base légale intérêt légitime droit accès effacement portabilité sanction mise en demeure sécurité").split()
+
+
+def query_texts(b: int, seed: int = 4321) -> list:
+    """b short question-like strings (8-24 words) for the encode leg of config C5; deterministic"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(b):
+        n = int(rng.integers(8, 25))
+        out.append("Quelle " + " ".join(_WORDS[int(i)] for i in rng.integers(0, len(_WORDS), n)) + " ?")
+    return out

@@ -180,3 +180,18 @@ def test_default_engine_fails_loudly_without_gpu():
     col = Collection("c")
     with pytest.raises(RdxUnavailable):
         col.add(ids=["a"], embeddings=[[1.0] * 64])
+
+
+def test_import_collection_pages_through_a_chroma_shaped_source(tmp_path, factory=oracle_factory):
+    from rag_dpo_amd.collection import PersistentClient, import_collection
+    src = PersistentClient(path=None, engine_factory=factory).create_collection("rag_dpo_chunks", metadata={"hnsw:space": "cosine"})
+    emb, ids, docs, metas = fill(src, n=230, dim=32)
+    src.delete(ids=ids[5:9])
+    dst_client = PersistentClient(path=str(tmp_path / "db"), engine_factory=factory)
+    dst = import_collection(src, dst_client, page=64)
+    a, b = src.get(include=["documents", "metadatas"]), dst.get(include=["documents", "metadatas"])
+    assert a["ids"] == b["ids"] and a["documents"] == b["documents"] and a["metadatas"] == b["metadatas"]
+    q = emb[:3].tolist()
+    assert src.query(query_embeddings=q, n_results=7)["ids"] == dst.query(query_embeddings=q, n_results=7)["ids"]
+    again = PersistentClient(path=str(tmp_path / "db"), engine_factory=factory).get_collection("rag_dpo_chunks")
+    assert again.get(include=[])["ids"] == a["ids"]
