@@ -12,8 +12,12 @@
  *     thread-local message of the last failure on the calling thread.
  *   - `space` says where EVERY pointer argument of that call lives: RDX_HOST or RDX_DEVICE
  *     (device = the index's HIP device). Caller owns all buffers.
- *   - `stream` is a hipStream_t passed as void* (NULL = the library's own stream for that index).
- *     RDX_HOST calls are synchronous; RDX_DEVICE calls are enqueued on `stream` and return at once.
+ *   - `stream` is a hipStream_t passed as void*. RDX_DEVICE calls run on exactly that stream (NULL =
+ *     HIP's default stream, as with any HIP API), i.e. ordered after whatever the caller enqueued
+ *     there to produce the inputs; rdx_search additionally synchronises the stream once before it
+ *     returns (overflow check). RDX_HOST calls are synchronous; NULL = the library's own stream.
+ *     Calls WITHOUT a stream argument (add / update / get / compact) given RDX_DEVICE pointers first
+ *     wait for all work enqueued on the device so far (hipDeviceSynchronize) and are complete on return.
  *   - rows are addressed by their insertion index ("row id", int64, 0-based); the Python layer
  *     maps row ids to Chroma string ids / documents / metadatas.
  *   - scores are cosine similarities in fp32: exact dot product of the two L2-normalised fp32

@@ -257,6 +257,7 @@ static const int64_t STAGE_ROWS = 32768;
 // normalise n rows (host or device, fp32 or bf16) into master/shadow at dst rows (row0.. or dst_ids)
 static int ingest(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int space, int64_t row0, const int64_t* d_dst_ids) {
     hipStream_t st = h->own_stream;
+    if (space == RDX_DEVICE) HIP_TRY(hipDeviceSynchronize());   // the caller's producers of `rows` (any stream) are done
     const size_t esz = is_bf16 ? 2 : 4;
     RDX_TRY(h->bad.ensure(sizeof(int)));
     HIP_TRY(hipMemsetAsync(h->bad.p, 0, sizeof(int), st));
@@ -306,6 +307,7 @@ static int stage_ids(rdx_index* h, const int64_t* ids, int64_t n, int space, con
     std::vector<int64_t> tmp;
     const int64_t* host_ids = ids;
     if (space == RDX_DEVICE) {
+        HIP_TRY(hipDeviceSynchronize());   // the caller's producers of `ids` (any stream) are done
         tmp.resize((size_t)n);
         HIP_TRY(hipMemcpy(tmp.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost));
         host_ids = tmp.data();
@@ -645,7 +647,8 @@ extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k,
     if (!queries || !out_count || (k > 0 && (!out_score || !out_row))) return fail(RDX_ERR_INVALID, "rdx_search: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
     RDX_TRY(set_device(h));
-    hipStream_t st = stream ? (hipStream_t)stream : h->own_stream;
+    // device pointers: the caller's stream as given (NULL = the default stream the caller produced its inputs on)
+    hipStream_t st = (space == RDX_DEVICE || stream) ? (hipStream_t)stream : h->own_stream;
     if (h->profile && !h->ev_ok) {
         for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
         h->ev_ok = true;

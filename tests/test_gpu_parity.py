@@ -277,3 +277,33 @@ def test_device_pointer_path_matches_host_path(eng):
     ix.set_option("row_base", 1000)
     s2, r2, c2 = ix.search(q[:3], 10)
     np.testing.assert_array_equal(r2, r[:3] + 1000)
+
+
+def test_device_queries_are_ordered_on_the_callers_stream(eng):
+    """The query tensor is still being produced on the caller's stream (default stream, then a side stream) when the
+    search is enqueued: the search must run behind it, not beside it (include/rdx.h: RDX_DEVICE calls run on `stream`)."""
+    import torch
+    corpus = synth.make_corpus(30000, 256)
+    q = synth.make_queries(8, 256, corpus)
+    ix = eng.HipIndex(256)
+    ix.add(corpus)
+    ix.set_option("force_fast", 1)
+    s, r, c = ix.search(q, 10)
+    base = torch.from_numpy(q).cuda()
+    w = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    for stream in (torch.cuda.default_stream(), torch.cuda.Stream()):
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            x = w
+            for _ in range(40):                      # tens of ms of GPU work in front of the queries
+                x = torch.tanh((x @ w) * 1e-2)
+            qd = torch.zeros_like(base)
+            qd += base + 0.0 * x[0, :1]              # ready only when the chain has finished
+            sd = torch.empty((8, 10), dtype=torch.float32, device="cuda")
+            rd = torch.empty((8, 10), dtype=torch.int64, device="cuda")
+            cd = torch.empty((8,), dtype=torch.int32, device="cuda")
+            ix.search_device(qd, 10, sd, rd, cd)
+        stream.synchronize()
+        np.testing.assert_array_equal(rd.cpu().numpy(), r)
+        np.testing.assert_array_equal(sd.cpu().numpy(), s)
