@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
     ap.add_argument("--no-encode", action="store_true", help="c5: leave the BGE-M3 query encode out of the step")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="developer: rdx_index_set_option before the run")
     ap.add_argument("--check-merged", action="store_true",
                     help="N>1: rank 0 also builds the WHOLE corpus in one index and checks that the merged result is bit-identical")
     args = ap.parse_args()
@@ -171,6 +172,8 @@ def main():
     searcher = ShardedSearcher(shard, host_staged=rehearsal)
     queries = synth.torch_queries(B, dim, device)
     shard.index.set_option("profile", 1)    # HIP events around every kernel, on the stream they run on
+    for kv in args.set:
+        shard.index.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
     def barrier():
         if world > 1:

@@ -82,7 +82,10 @@ int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep);
 /* Options (tests and benchmarks): "force_exact" 0/1, "force_fast" 0/1 (MFMA scan even for small
  * problems), "sample_div" >=1, "cand_cap" 0 (auto) or slots per (query, stream) candidate segment,
  * "profile" 0/1 (record HIP events around every kernel of the next searches); "row_base" >= 0:
- * added to every returned row id, so a shard holding rows [base, base+count) answers with GLOBAL ids. */
+ * added to every returned row id, so a shard holding rows [base, base+count) answers with GLOBAL ids;
+ * "sib_sync" 0/1 (default 0) and "sib_lag" 3..100 (k-steps): soft lock-step of the workgroups that stream
+ * the same corpus tiles for different query tiles (less fabric traffic for ~2-3 % of the throughput while the
+ * launch is MFMA-bound; speed and traffic only, never results). */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);
 
 /* `SentenceTransformer.encode(..., normalize_embeddings=True)`'s last step

@@ -89,13 +89,13 @@ struct rdx_index {
     std::mutex mu;
 
     // options
-    int force_exact = 0, force_fast = 0, profile = 0;
+    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6;
     int sample_div = 64;
     int64_t cand_cap = 0;   // 0 = automatic
     int64_t row_base = 0;   // added to every returned row id (global ids of a shard)
 
     // scratch (grow-only; never allocated inside a warmed-up search)
-    DevBuf staging, qraw, qhat, qshadow, tau, cntw, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
+    DevBuf sib_scratch, staging, qraw, qhat, qshadow, tau, cntw, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
         o_count, mask, ids;
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
@@ -234,6 +234,8 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     const std::string n(name);
     if (n == "force_exact") h->force_exact = value != 0;
     else if (n == "force_fast") h->force_fast = value != 0;
+    else if (n == "sib_sync") h->sib_sync = value != 0;
+    else if (n == "sib_lag") h->sib_lag = (int)std::min<int64_t>(std::max<int64_t>(value, 3), 100);
     else if (n == "profile") h->profile = value != 0;
     else if (n == "sample_div") {
         if (value < 1) return fail(RDX_ERR_INVALID, "sample_div must be >= 1");
@@ -443,11 +445,11 @@ extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim,
 // ------------------------------------------------------------------------------------------------
 // search
 // ------------------------------------------------------------------------------------------------
-template <int BN, int EPI, bool RES>
+template <int BN, int EPI, bool RES, bool SIBT = false>
 static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t st) {
     // LDS: query-image ring (or the whole resident query tile) + BN hit counters + BN thresholds
     const size_t lds = (size_t)(RES ? p.ksteps : RING_SLOTS) * BN * BK * 2 + BN * 8;
-    void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES> : k_scan<BN, EPI, false, RES>;
+    void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES, SIBT> : k_scan<BN, EPI, false, RES, SIBT>;
     static size_t lds_set[2] = {0, 0};   // per instantiation: raise the dynamic-LDS limit once per size (RES sizes vary with dim)
     if (lds_set[p.allow ? 1 : 0] < lds) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -462,6 +464,7 @@ template <int EPI>
 static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, int grid, hipStream_t st) {
     if (bn == 64) return res ? launch_scan<64, EPI, true>(h, p, grid, st) : launch_scan<64, EPI, false>(h, p, grid, st);
     if (bn == 128) return launch_scan<128, EPI, false>(h, p, grid, st);
+    if (EPI == EPI_EMIT && p.sib) return launch_scan<256, EPI, false, EPI == EPI_EMIT>(h, p, grid, st);
     return launch_scan<256, EPI, false>(h, p, grid, st);
 }
 
@@ -496,11 +499,13 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     // K1 on the queries: qhat (fp32, exact re-score) + tiled fp16 copy (scan)
     RDX_TRY(h->qhat.ensure((size_t)nq_pad * h->dim * 4));
     RDX_TRY(h->qshadow.ensure((size_t)nq_pad * h->dim_pad * 2));
-    RDX_TRY(h->ctr.ensure(sizeof(RefineCounters)));
+    constexpr size_t SIB_OFF = 64, SIB_BYTES = (size_t)REFINE_STREAMS * 16;   // counters | sibling progress bytes
+    static_assert(sizeof(RefineCounters) <= SIB_OFF, "counter block layout");
+    RDX_TRY(h->ctr.ensure(SIB_OFF + SIB_BYTES));
     RDX_TRY(h->exact_list.ensure((size_t)nq_pad * 4));
     int* d_bad = reinterpret_cast<int*>(h->ctr.as<char>() + offsetof(RefineCounters, bad));
     mark(0);
-    HIP_TRY(hipMemsetAsync(h->ctr.p, 0, sizeof(RefineCounters), st));   // the only memset of a search (counters + NaN flag)
+    HIP_TRY(hipMemsetAsync(h->ctr.p, 0, SIB_OFF + SIB_BYTES, st));   // the only memset of a search (counters, NaN flag, sibling progress)
     hipLaunchKernelGGL(k_normalize<true>, dim3((int)((nq_pad + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
                        (const int64_t*)nullptr, (int64_t)0, h->qhat.as<float>(), h->qshadow.as<_Float16>(), h->ksteps, h->scale(),
                        d_bad, (int64_t)nq_pad);
@@ -576,6 +581,10 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         p.cand = h->cand.as<uint2>();
         p.capw = capw;
         p.inv_scale2 = std::ldexp(1.0f, -2 * h->scale_log2);
+        p.sib_lag = h->sib_lag;
+        RDX_TRY(h->sib_scratch.ensure((size_t)REFINE_STREAMS * 16 * 8));
+        p.sib_scratch = h->sib_scratch.as<uint8_t>();
+        p.sib = (nqt > 1 && nqt <= 16 && h->ksteps >= 4 && h->sib_sync) ? reinterpret_cast<uint32_t*>(h->ctr.as<char>() + SIB_OFF) : nullptr;
 
         p.tile_stride = div;
         RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn, res, p, grid, st));

@@ -77,6 +77,9 @@ struct ScanParams {
     uint2* cand;               // [nq_pad][n_streams][capw] (score bits, row)
     uint32_t capw;
     float inv_scale2;          // accumulator -> score
+    uint32_t* sib;             // [n_streams][4] progress bytes of the query-tile workgroups of a stream (zeroed per launch), or NULL
+    uint8_t* sib_scratch;      // [n_streams][16][8] bytes nobody reads (keeps the per-wave operation counts uniform)
+    int sib_lag;               // throttle when the slowest sibling looks more than this many k-steps behind (a snapshot is ~2-3 old)
 };
 
 // row inside a 32x32 MFMA block held by accumulator register r of a lane in half h (= lane >> 5)
@@ -93,12 +96,25 @@ __device__ __forceinline__ void wait_vmcnt_keep(half8 (&a)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory");
 }
 
-template <int BN, int EPI, bool HAS_MASK, bool RES>
+template <int BN, int EPI, bool HAS_MASK, bool RES, bool SIBT = false>
 __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     constexpr int NBN = BN / 32;          // 32-query blocks per wave (a wave owns 32 rows x all BN queries)
     constexpr int B_BYTES = BN * BK * 2;  // one k-step image of this workgroup's queries
     constexpr int NPB = BN / 64;          // 1 KiB DMA pieces per wave per query image
-    constexpr int V = 4 + (RES ? 0 : NPB);   // vector-memory operations a wave issues per k-step
+    // Sibling lock-step (speed only). The nqt workgroups of a stream read the same corpus tiles; nothing else keeps them
+    // together, and once they drift by more than the L2 can hold (8 streams x 16 KiB per k-step per XCD) every one of
+    // them fetches its own copy over the fabric. Each workgroup therefore publishes the number of k-steps it has finished
+    // (one byte, mod 256) and every wave reads the four bytes of its sibling group once per k-step — one more counted
+    // vector-memory operation, consumed two steps later behind the wait that is there anyway — and naps while the slowest
+    // sibling is more than sib_lag steps behind. The nap is bounded: a sibling that never shows up (not co-resident)
+    // switches the mechanism off for this wave, so every wave reaches its exit whatever the others do.
+    // Measured at 10M x 1024, B = 1024 (same box, alternating): fabric traffic per launch 42.0 GB -> 29.7 GB (2.05x -> 1.45x
+    // the algorithmic bytes) at sib_lag 6, queries/s -2.6 % (two more vector-memory instructions per wave and k-step ~1.2 %,
+    // the rest is running at the pace of the momentarily slowest sibling). The launch is MFMA-bound at a third of the
+    // fabric's bandwidth, so this variant (SIBT) is selected only when option "sib_sync" is set.
+    constexpr bool SIB = SIBT && EPI == EPI_EMIT && !RES && BN == 256;
+    constexpr int SIBN = SIB ? 2 : 0;                  // its vector-memory operations per wave and k-step: one store, one load
+    constexpr int V = 4 + (RES ? 0 : NPB) + SIBN;      // vector-memory operations a wave issues per k-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- which stream / query tile am I (XCD-aware: blocks with equal blockIdx % 8 share an L2) ----
@@ -121,6 +137,21 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     const int my_tiles = stream < n_sched ? (n_sched - stream + n_streams - 1) / n_streams : 0;
     const int KS = p.ksteps;
     const int total = my_tiles * KS;   // k-steps of this workgroup (host keeps tiles*ksteps < 2^31)
+    const uint32_t* sib_word = p.sib ? p.sib + stream * 4 + (qt >> 2) : p.cntw;   // (any valid word when the mechanism is off)
+    const int sib_n = p.nqt - (qt & ~3) < 4 ? p.nqt - (qt & ~3) : 4;             // workgroups in my sibling group
+    bool sib_on = SIB && p.sib != nullptr && p.nqt > 1;
+    const uint8_t* sib_pub = (wave == 0 && p.sib) ? reinterpret_cast<const uint8_t*>(sib_word) + (qt & 3)
+                                                  : p.sib_scratch + ((stream * 16 + (qt & 15)) * 8 + wave);
+    const int zero_off = 0;
+    auto sib_lag = [&](uint32_t word, int s_mine) {   // k-steps the slowest sibling of the snapshot is behind s_mine (mod 256)
+        int lag = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = (int)(int8_t)(uint8_t)((uint32_t)s_mine - (word >> (8 * j)));
+            if (j < sib_n && d > lag) lag = d;
+        }
+        return lag;
+    };
 
     const int ring_bytes = (RES ? KS : RING_SLOTS) * B_BYTES;
     uint32_t* lcnt = reinterpret_cast<uint32_t*>(smem + ring_bytes);   // [BN] hit counters of this (stream, query tile)
@@ -265,10 +296,32 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 #pragma unroll
         for (int g = 0; g < PD; ++g) load_group(smem, g, bf[g]);   // step 0 reads slot 0 / k-step image 0
 
-        auto step = [&](half8 (&af)[4], int s) {
+        uint32_t poll0 = 0, poll1 = 0;   // sibling snapshots in flight (even / odd steps)
+        auto step = [&](half8 (&af)[4], uint32_t& poll, int s) {
             // my corpus fragments of this step have landed (issued two steps ago); the V operations of the previous step
             // stay in flight. No barrier here: the query image of step s was certified by the mid-step barrier of step s-1.
             wait_vmcnt_keep<V>(af);
+            if constexpr (SIB) {
+                asm volatile("" : "+v"(poll));   // the snapshot requested two steps ago has landed with the fragments
+                if (sib_on && sib_lag(__builtin_amdgcn_readfirstlane(poll), s) > p.sib_lag) {
+                    int naps = 0;
+                    while (true) {
+                        __builtin_amdgcn_s_sleep(8);
+                        const uint32_t w = __hip_atomic_load(sib_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (sib_lag(__builtin_amdgcn_readfirstlane(w), s) <= p.sib_lag - 3) break;
+                        if (++naps > 1000) {   // ~0.5 ms: the sibling is not running beside us; stop caring
+                            sib_on = false;
+                            break;
+                        }
+                    }
+                }
+                // publish "this workgroup has finished s k-steps". EVERY wave issues one byte store per step so that the counted
+                // waits are the same for all of them (an uncounted store would make wave 0 wait for a corpus load issued
+                // half a step ago, every step: -5 %); waves 1..7 write to a scratch byte nobody reads. Plain store: the byte
+                // stays in this XCD's L2, where the siblings' sc1 (L1-bypassing) loads find it; inline asm: a volatile C++
+                // store becomes flat_store sc0 sc1 + s_waitcnt vmcnt(0).
+                if (lane == 0) asm volatile("global_store_byte %0, %1, %2" ::"v"(zero_off), "v"(s), "s"(sib_pub) : "memory");
+            }
             const int ksn = ks + 1 == KS ? 0 : ks + 1;
             const char* st = smem + (RES ? ks : slot_c) * B_BYTES;
             const char* stn = smem + (RES ? ksn : ((slot_c + 1) & 3)) * B_BYTES;   // image of step s+1
@@ -285,7 +338,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                         // the V of step s-1, A0 A1 of this step). After the barrier every wave's pieces of image s+1 have
                         // landed and every wave has left step s-1, whose ring slot is refilled with image s+3.
                         __builtin_amdgcn_sched_barrier(0);
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + V) : "memory");
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + SIBN + V) : "memory");
                         __builtin_amdgcn_s_barrier();
 #if !defined(RDX_ABL_NOB) && !RDX_SPREAD_DMA
                         if (!RDX_DMA_STAGGER || !dma_late) issue_b(ksb, (slot_c + 3) & 3);
@@ -343,6 +396,9 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 #elif RDX_MFMA16
                     gload16(af[2 * kk], an + (2 * kk) * 1024);
                     gload16(af[2 * kk + 1], an + (2 * kk + 1) * 1024);
+                    if constexpr (SIB) {
+                        if (kk == 0) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(poll) : "v"(zero_off), "s"(sib_word) : "memory");
+                    }
 #else
                     gload16(af[kk], an + kk * 1024);
 #endif
@@ -467,7 +523,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 #endif
         };
 
-        auto advance = [&]() {
+        auto advance = [&](int) {
             const bool last_k = ks == KS - 1;
             const int it_done = it;
             if (++ks == KS) { ks = 0; ++it; }
@@ -480,17 +536,18 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         // steps alternate between the two fragment register sets
         int s = 0;
         for (; s + 1 < total; s += 2) {
-            step(a0, s);
-            advance();
-            step(a1, s + 1);
-            advance();
+            step(a0, poll0, s);
+            advance(s);
+            step(a1, poll1, s + 1);
+            advance(s + 1);
         }
         if (s < total) {
-            step(a0, s);
-            advance();
+            step(a0, poll0, s);
+            advance(s);
         }
         // drain the never-consumed tail prefetches; naming all eight fragments keeps their registers reserved until here
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3])
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
+                     "v"(poll0), "v"(poll1)
                      : "memory");
     }
 

@@ -307,3 +307,22 @@ def test_device_queries_are_ordered_on_the_callers_stream(eng):
         stream.synchronize()
         np.testing.assert_array_equal(rd.cpu().numpy(), r)
         np.testing.assert_array_equal(sd.cpu().numpy(), s)
+
+
+def test_sibling_lockstep_variant_is_exact(eng, oracle):
+    """option sib_sync selects the scan variant whose query-tile workgroups keep in step (speed/traffic only): same bits"""
+    corpus = synth.make_corpus(70000, 1024)
+    q = synth.make_queries(700, 1024, corpus)          # 3 query tiles of 256 -> three sibling workgroups per stream
+    ix = eng.HipIndex(1024)
+    ix.add(corpus)
+    es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, 10)
+    for lag in (3, 6):
+        ix.set_option("sib_sync", 1)
+        ix.set_option("sib_lag", lag)
+        s, r, c = ix.search(q, 10)
+        assert ix.last_stats()["path"] == 0
+        np.testing.assert_array_equal(r, er)
+        np.testing.assert_array_equal(s, es)
+    ix.set_option("sib_sync", 0)
+    s, r, c = ix.search(q, 10)
+    np.testing.assert_array_equal(r, er)
