@@ -88,12 +88,22 @@ class ShardedSearcher:
         c = buf[nq * k * 12: nq * k * 12 + nq * 4].view(torch.int32)
         return s, r, c
 
-    def search(self, queries: torch.Tensor, k: int):
+    def search(self, queries: torch.Tensor, k: int, query_src: Optional[int] = None):
         """queries: [nq][dim] fp32 on self.device, identical on every rank; k >= 1. Returns (score, row, count)
-        tensors with GLOBAL row ids, identical on every rank."""
+        tensors with GLOBAL row ids, identical on every rank.
+        query_src = r: only rank r's `queries` holds the batch (the rank that took the request); the other ranks pass a
+        tensor of the same shape to receive it — one broadcast (B*d*4 bytes: 4 MB at B = 1024) in front of the scan
+        (SURVEY.md §8e)."""
         if k < 1:
             raise ValueError("k must be >= 1")
         nq = queries.shape[0]
+        if query_src is not None and self.world > 1:
+            if self.host_staged:
+                h_q = queries.cpu()
+                dist.broadcast(h_q, src=query_src, group=self.group)
+                queries.copy_(h_q)
+            else:
+                dist.broadcast(queries, src=query_src, group=self.group)
         per_pad, local, allb, out = self._buffers(nq, k)
         s, r, c = self.views(local, nq, k)
         self.shard.search(queries, k, s, r, c)

@@ -57,7 +57,13 @@ def _worker(rank, world, port, n, dim, b, k, out_dir):
     q = torch.from_numpy(synth.make_queries(b, dim, corpus))
     lo, hi = shard_range(n, world, rank)
     ss = ShardedSearcher(OracleShard(corpus[lo:hi], lo))
-    s, r, c = ss.search(q, k)
+    if rank == 0:
+        s, r, c = ss.search(q, k, query_src=0)                      # the rank that took the request
+    else:
+        s, r, c = ss.search(torch.zeros_like(q), k, query_src=0)    # the others receive the batch
+    s, r, c = s.clone(), r.clone(), c.clone()
+    s2, r2, c2 = ss.search(q, k)                                    # replicated batch, no broadcast
+    assert torch.equal(r, r2) and torch.equal(s, s2) and torch.equal(c, c2)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), c=c.numpy())
     dist.barrier()
     dist.destroy_process_group()
