@@ -187,7 +187,7 @@ def main():
     if encode:
         from rag_dpo_amd.embedding_provider import EmbeddingProvider
         provider = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device=str(device), dtype=torch.float16,
-                                     batch_size=256).load()
+                                     batch_size=int(os.environ.get("RDX_ENC_BATCH", "512"))).load()
         texts = synth.query_texts(B)
 
     def step():
