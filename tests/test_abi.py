@@ -39,3 +39,17 @@ def test_error_convention_without_gpu():
         assert L.rdx_index_create(0, 1024, ctypes.byref(h)) != 0
     assert L.rdx_index_create(0, 1023, ctypes.byref(ctypes.c_void_p())) == _lib.RDX_ERR_INVALID   # dim % 4
     assert "multiple of 4" in _lib.last_error()
+
+
+def test_scan_kernels_do_not_spill():
+    """the scan kernels keep inline-asm loads in flight across many instructions: a register spill in them can save and
+    restore a value that has not landed yet (silently wrong ids). The build refuses such a library; this pins the
+    figures it recorded (rag_dpo_amd/build.py)."""
+    import json
+    from rag_dpo_amd import build
+    build.build_lib()
+    res = json.load(open(build.RESOURCES))
+    scans = {k: v for k, v in res.items() if "k_scan" in k}
+    assert len(scans) >= 16, sorted(scans)
+    for k, v in scans.items():
+        assert v["spill_vgprs"] == 0 and v["scratch_bytes"] == 0 and v["vgprs"] <= 256, (k, v)
