@@ -69,6 +69,22 @@ def build_shard(shard: HipShard, lo: int, hi: int, dim: int, corpus_kind: str, d
     torch.cuda.synchronize(device)
 
 
+def effective_cpus() -> int:
+    """host cores this process may really use: min(os.cpu_count(), affinity mask, cgroup cpu.max quota)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, total_rows: int):
     """rank 0, N=1 only. The oracle is the CHECKER and the timed CPU baseline; never the thing shipped."""
     from oracle import oracle as O
@@ -80,16 +96,18 @@ def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, to
     q = queries.cpu().numpy()
     qhat = O.normalize_rows(q)
     # --- CPU baseline: fp32 BLAS sgemm + partial sort on all host cores, bounded sample, scaled to the full corpus
-    threads = os.cpu_count() or 1
+    threads = effective_cpus()
     bq = min(B, 1024)
     t_best, reps = None, 0
     t_end = time.time() + 12.0
-    while reps < 3 or (time.time() < t_end and reps < 20):
-        t0 = time.time()
-        O.topk_blas_f32(rows_hat, qhat[:bq], min(k, sample))
-        dt = time.time() - t0
-        t_best = dt if t_best is None else min(t_best, dt)
-        reps += 1
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=threads):
+        while reps < 3 or (time.time() < t_end and reps < 20):
+            t0 = time.time()
+            O.topk_blas_f32(rows_hat, qhat[:bq], min(k, sample))
+            dt = time.time() - t0
+            t_best = dt if t_best is None else min(t_best, dt)
+            reps += 1
     qps_sample = bq / t_best
     cpu = {
         "value": round(qps_sample * sample / total_rows, 2), "unit": "queries/s", "cores": threads, "kind": "port",
