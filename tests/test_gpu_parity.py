@@ -326,3 +326,19 @@ def test_sibling_lockstep_variant_is_exact(eng, oracle):
     ix.set_option("sib_sync", 0)
     s, r, c = ix.search(q, 10)
     np.testing.assert_array_equal(r, er)
+
+
+def test_zero_and_tiny_query_vectors(eng, oracle):
+    """a zero query (norm clamps at 1e-12, every score 0 -> the first k rows by the tie rule), a denormal-scale query
+    and a huge-scale query answer exactly as the oracle does, also when the MFMA path is forced (emits everything ->
+    overflow -> exact fallback)"""
+    corpus = synth.make_corpus(50000, 1024)
+    q = synth.make_queries(6, 1024, corpus)
+    q[0] = 0.0
+    q[1] *= 1e-30
+    q[2] *= 1e30
+    q[3, 1:] = 0.0            # a single non-zero component
+    for force in (0, 1):
+        ix = _index(eng, corpus, force_fast=force)
+        _check(oracle, ix, corpus, q, 10)
+        ix.close()
