@@ -85,7 +85,8 @@ int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep);
  * added to every returned row id, so a shard holding rows [base, base+count) answers with GLOBAL ids;
  * "sib_sync" 0/1 (default 0) and "sib_lag" 3..100 (k-steps): soft lock-step of the workgroups that stream
  * the same corpus tiles for different query tiles (less fabric traffic for ~2-3 % of the throughput while the
- * launch is MFMA-bound; speed and traffic only, never results). */
+ * launch is MFMA-bound; speed and traffic only, never results); "retry" 0/1 (default 1): queries whose candidate
+ * segments overflow get a second MFMA pass as a small batch (denser threshold sample) before the exact full scan. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);
 
 /* `SentenceTransformer.encode(..., normalize_embeddings=True)`'s last step
@@ -127,6 +128,7 @@ typedef struct rdx_search_stats {
     int32_t profiled;         /* 1 if the ms_* fields below were measured */
     float ms_normalize, ms_scan_sample, ms_tau, ms_scan_main, ms_refine, ms_exact, ms_total;
     int64_t scan_main_launch_rows, scan_main_launch_queries; /* units of the dominant kernel */
+    int64_t retried_queries;  /* queries whose candidate segments overflowed and that got a second MFMA pass */
 } rdx_search_stats;
 int rdx_search_last_stats(rdx_index* h, rdx_search_stats* out);
 

@@ -33,6 +33,7 @@ class SearchStats(ctypes.Structure):
         ("ms_scan_main", ctypes.c_float), ("ms_refine", ctypes.c_float), ("ms_exact", ctypes.c_float),
         ("ms_total", ctypes.c_float),
         ("scan_main_launch_rows", ctypes.c_int64), ("scan_main_launch_queries", ctypes.c_int64),
+        ("retried_queries", ctypes.c_int64),
     ]
 
     def as_dict(self):

@@ -89,12 +89,13 @@ struct rdx_index {
     std::mutex mu;
 
     // options
-    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6;
+    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1;
     int sample_div = 64;
     int64_t cand_cap = 0;   // 0 = automatic
     int64_t row_base = 0;   // added to every returned row id (global ids of a shard)
 
     // scratch (grow-only; never allocated inside a warmed-up search)
+    DevBuf r_list, r_q, r_s, r_r, r_c;   // second-chance batch of overflowed queries
     DevBuf sib_scratch, staging, qraw, qhat, qshadow, tau, cntw, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
         o_count, mask, ids;
     hipEvent_t ev[8] = {};
@@ -235,6 +236,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     if (n == "force_exact") h->force_exact = value != 0;
     else if (n == "force_fast") h->force_fast = value != 0;
     else if (n == "sib_sync") h->sib_sync = value != 0;
+    else if (n == "retry") h->retry = value != 0;
     else if (n == "sib_lag") h->sib_lag = (int)std::min<int64_t>(std::max<int64_t>(value, 3), 100);
     else if (n == "profile") h->profile = value != 0;
     else if (n == "sample_div") {
@@ -489,10 +491,11 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
     return RDX_OK;
 }
 
+// depth 0 = the caller's batch; depth 1 = the second-chance batch of queries whose candidate segments overflowed
 static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k, const uint32_t* d_allow, float* d_score,
-                        int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats) {
+                        int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth = 0) {
     const int nq_pad = (int)((nq + 255) / 256 * 256);
-    const bool prof = h->profile != 0;
+    const bool prof = h->profile != 0 && depth == 0;
     auto mark = [&](int i) {
         if (prof) (void)hipEventRecord(h->ev[i], st);
     };
@@ -552,12 +555,14 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         // per query (~1.3 k rows/sample_rows) around 4000/... of the refine list and the sample >= max(64k, 8192) rows
         const int64_t want_rows = std::max<int64_t>(64 * (int64_t)k, 8192);
         int div = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(h->sample_div, h->rows / want_rows), 3000 / std::max(k, 1)));
+        if (depth > 0) div = std::max(1, div / 8);   // second chance: 8x denser sample -> a threshold that sees the cluster
         const int64_t n_sched = (n_tiles + div - 1) / div;
         sample_rows = n_sched * 256;
         const int n_sets_used = (int)std::min<int64_t>(n_streams, n_sched) * SETS_PER_STREAM;
         // slots per (query, stream) segment: 8x the expected hits, power of two, [32, 4096]
         const double exp_hits = (1.5 * k * (double)h->rows / (double)std::max<int64_t>(sample_rows, 1) + k) / n_streams;
-        uint32_t capw = 32;
+        // (slots cost address space, not bandwidth: only occupied slots are ever touched)
+        uint32_t capw = depth > 0 ? 2048 : 256;
         while (capw < 4096 && capw < 8.0 * exp_hits) capw *= 2;
         if (h->cand_cap) capw = (uint32_t)std::min<int64_t>(h->cand_cap, 1 << 16);
         RDX_TRY(h->tau.ensure((size_t)nq_pad * 4));
@@ -615,7 +620,34 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         n_exact = ctr.n_exact;
-        if (n_exact > 0) RDX_TRY(run_exact(h, h->exact_list.as<int32_t>(), n_exact, k, d_allow, d_score, d_row, d_count, st));
+        if (n_exact > 0 && depth == 0 && h->retry && n_exact <= 256) {
+            // Overflow means "far more rows above the sampled threshold than expected": similar rows stored together
+            // (chunks of one document) that the sparse sample missed. Before paying the exact full scan (one fp32 pass over
+            // the corpus per 4 queries), give exactly these queries one more MFMA pass as a small, HBM-bound batch with a
+            // denser sample and larger segments; what overflows again goes to the exact scan inside that call.
+            const int m = n_exact, kk = std::max(k, 1);
+            RDX_TRY(h->r_list.ensure((size_t)m * 4));
+            RDX_TRY(h->r_q.ensure((size_t)m * h->dim * 4));
+            RDX_TRY(h->r_s.ensure((size_t)m * kk * 4));
+            RDX_TRY(h->r_r.ensure((size_t)m * kk * 8));
+            RDX_TRY(h->r_c.ensure((size_t)m * 4));
+            HIP_TRY(hipMemcpyAsync(h->r_list.p, h->exact_list.p, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_gather_queries, dim3((m + 3) / 4), dim3(256), 0, st, d_queries, h->r_list.as<int32_t>(), m, h->dim,
+                               h->r_q.as<float>());
+            HIP_TRY(hipGetLastError());
+            rdx_search_stats sub = {};
+            RDX_TRY(search_chunk(h, h->r_q.as<float>(), m, k, d_allow, h->r_s.as<float>(), h->r_r.as<int64_t>(), h->r_c.as<int32_t>(), st,
+                                 &sub, 1));
+            hipLaunchKernelGGL(k_scatter_topk, dim3(m), dim3(64), 0, st, h->r_s.as<float>(), h->r_r.as<int64_t>(), h->r_c.as<int32_t>(),
+                               h->r_list.as<int32_t>(), m, k, d_score, d_row, d_count);
+            HIP_TRY(hipGetLastError());
+            acc_stats->retried_queries += m;
+            acc_stats->emitted += sub.emitted;
+            acc_stats->rescored += sub.rescored;
+            n_exact = (int)sub.exact_queries;
+        } else if (n_exact > 0) {
+            RDX_TRY(run_exact(h, h->exact_list.as<int32_t>(), n_exact, k, d_allow, d_score, d_row, d_count, st));
+        }
         acc_stats->scan_main_launch_rows = h->rows;
         acc_stats->scan_main_launch_queries = nq;
     }

@@ -109,6 +109,32 @@ __global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, 
     rank_and_write(s_s, s_r, p, k, o_s, o_r, out_count + q);
 }
 
+// Second chance for queries whose candidate segments overflowed: their raw vectors are gathered into a small batch
+// (one wave per query) ...
+__global__ __launch_bounds__(256) void k_gather_queries(const float* __restrict__ queries, const int32_t* __restrict__ list, int m,
+                                                        int dim, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const float4* src = reinterpret_cast<const float4*>(queries + (int64_t)list[i] * dim);
+    float4* dst = reinterpret_cast<float4*>(out + (int64_t)i * dim);
+    for (int g = lane; g < (dim >> 2); g += 64) dst[g] = src[g];
+}
+// ... and the batch's answers are put back where those queries belong
+__global__ __launch_bounds__(256) void k_scatter_topk(const float* __restrict__ s, const int64_t* __restrict__ r,
+                                                      const int32_t* __restrict__ c, const int32_t* __restrict__ list, int m, int k,
+                                                      float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                                      int32_t* __restrict__ out_count) {
+    const int i = blockIdx.x;
+    if (i >= m) return;
+    const int64_t q = list[i];
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        out_score[q * k + j] = s[(int64_t)i * k + j];
+        out_row[q * k + j] = r[(int64_t)i * k + j];
+    }
+    if (threadIdx.x == 0) out_count[q] = c[i];
+}
+
 // C1. merge n_parts partial top-k lists per query. One block per query; n_parts*k <= MERGE_MAX.
 // part p of each array starts stride_* ELEMENTS after part p-1 (contiguous [n_parts][nq][k] arrays, or the
 // packed all-gather receive buffer).

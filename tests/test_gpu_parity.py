@@ -342,3 +342,25 @@ def test_zero_and_tiny_query_vectors(eng, oracle):
         ix = _index(eng, corpus, force_fast=force)
         _check(oracle, ix, corpus, q, 10)
         ix.close()
+
+
+def test_clustered_rows_get_a_second_mfma_pass(eng, oracle):
+    """similar rows stored together (chunks of one document) between two sampled tiles: the sparse threshold sample misses
+    them, their candidate segments overflow, and those queries — only those — are answered by a second MFMA pass with
+    a denser sample instead of the exact full scan. Results are the oracle's either way."""
+    rng = np.random.default_rng(11)
+    n, dim, k = 300_000, 256, 10
+    corpus = rng.standard_normal((n, dim)).astype(np.float32)
+    v = rng.standard_normal(dim).astype(np.float32)
+    a, m = 37 * 256, 20 * 256                      # tiles 37..56: none of them is a multiple of the sampling stride (36)
+    sigma = rng.uniform(0.2, 0.6, size=(m, 1)).astype(np.float32)
+    corpus[a:a + m] = v + sigma * rng.standard_normal((m, dim)).astype(np.float32)
+    q = rng.standard_normal((40, dim)).astype(np.float32)
+    q[:5] = v + 0.1 * rng.standard_normal((5, dim)).astype(np.float32)
+    ix = _index(eng, corpus, force_fast=1, cand_cap=64)
+    st = _check(oracle, ix, corpus, q, k, expect_path=0)
+    assert st["retried_queries"] == 5 and st["exact_queries"] == 0, st
+    ix.set_option("retry", 0)                      # without the second chance the same queries pay the exact scan
+    st = _check(oracle, ix, corpus, q, k, expect_path=0)
+    assert st["retried_queries"] == 0 and st["exact_queries"] == 5, st
+    ix.close()
