@@ -562,9 +562,10 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         // slots per (query, stream) segment: 8x the expected hits, power of two, [32, 4096]
         const double exp_hits = (1.5 * k * (double)h->rows / (double)std::max<int64_t>(sample_rows, 1) + k) / n_streams;
         // (slots cost address space, not bandwidth: only occupied slots are ever touched)
-        uint32_t capw = depth > 0 ? 2048 : 256;
+        // (nq_pad * n_streams is 65,536 whatever the batch: 1024 slots = 512 MiB, 4096 = 2 GiB of the 288)
+        uint32_t capw = depth > 0 ? 4096 : 1024;
         while (capw < 4096 && capw < 8.0 * exp_hits) capw *= 2;
-        if (h->cand_cap) capw = (uint32_t)std::min<int64_t>(h->cand_cap, 1 << 16);
+        if (h->cand_cap && depth == 0) capw = (uint32_t)std::min<int64_t>(h->cand_cap, 1 << 16);
         RDX_TRY(h->tau.ensure((size_t)nq_pad * 4));
         RDX_TRY(h->cntw.ensure((size_t)nq_pad * n_streams * 4));
         RDX_TRY(h->cand.ensure((size_t)nq_pad * n_streams * capw * 8));
@@ -620,7 +621,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         n_exact = ctr.n_exact;
-        if (n_exact > 0 && depth == 0 && h->retry && n_exact <= 256) {
+        if (n_exact > 0 && depth == 0 && h->retry) {
             // Overflow means "far more rows above the sampled threshold than expected": similar rows stored together
             // (chunks of one document) that the sparse sample missed. Before paying the exact full scan (one fp32 pass over
             // the corpus per 4 queries), give exactly these queries one more MFMA pass as a small, HBM-bound batch with a

@@ -135,7 +135,10 @@ def test_candidate_overflow_falls_back(eng, oracle):
     q = synth.make_queries(64, 1024, corpus)
     ix = _index(eng, corpus, force_fast=1, cand_cap=1)      # one slot per (query, stream) segment cannot hold k=50's hits
     st = _check(oracle, ix, corpus, q, 50, expect_path=0)
-    assert st["exact_queries"] > 0
+    assert st["retried_queries"] > 0                       # overflowed queries get the second MFMA pass (own, large segments)
+    ix.set_option("retry", 0)
+    st = _check(oracle, ix, corpus, q, 50, expect_path=0)
+    assert st["exact_queries"] > 0 and st["retried_queries"] == 0   # ... or the exact full scan when that is switched off
 
 
 def test_update_get_compact(eng, oracle):
