@@ -603,9 +603,9 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, res, p, grid, st));
         mark(4);
         {
-            // LDS list of the gathered hits: 4x the expected count (occupancy of the refine kernel), at most REFINE_LIST
+            // LDS list of the gathered hits: 16x the expected count (heavy-tailed score distributions of structured corpora; a list overflow costs a second pass), at most REFINE_LIST
             uint32_t list_cap = 1024;
-            while (list_cap < (uint32_t)REFINE_LIST && list_cap < 4.0 * exp_hits * n_streams) list_cap *= 2;
+            while (list_cap < (uint32_t)REFINE_LIST && list_cap < 16.0 * exp_hits * n_streams) list_cap *= 2;
             const size_t lds = (size_t)list_cap * 8;
             static size_t refine_lds = 0;
             if (refine_lds < lds) {
