@@ -37,3 +37,23 @@ def test_embed_unit_norm_and_k1_parity(oracle):
     assert p.embed_query(texts[0]) == out[0] and p.is_loaded
     p.unload()
     assert not p.is_loaded
+
+
+@pytest.mark.gpu
+def test_embed_device_feeds_the_index_without_the_list_round_trip(oracle):
+    """embed_device() hands the raw CLS embeddings to the device index directly; the index normalises them with the same
+    K1 — so the stored rows equal the embed() -> lists -> add() route up to that route's second normalisation (1 ulp) and
+    the neighbours are the same"""
+    from rag_dpo_amd.engine import HipIndex
+    p = EP.EmbeddingProvider(model_name="random-init:tiny", device="cuda").load()   # dims are known once the model is loaded
+    texts = [f"chunk numéro {i} sur la durée de conservation" for i in range(300)]
+    a, b = HipIndex(p.dims), HipIndex(p.dims)
+    a.add(np.asarray(p.embed(texts), dtype=np.float32))
+    b.add(p.embed_device(texts))
+    rows = np.arange(300)
+    np.testing.assert_allclose(a.get(rows), b.get(rows), rtol=0, atol=2.5e-7)
+    np.testing.assert_array_equal(b.get(rows), oracle.normalize_rows(p.embed_device(texts).cpu().numpy()))   # one K1, bit for bit
+    q = np.asarray(p.embed(["durée de conservation ?"]), dtype=np.float32)
+    sa, sb = a.search(q, 5), b.search(q, 5)
+    np.testing.assert_array_equal(sa[1], sb[1])
+    assert p.embed_device([]).shape == (0, p.dims)
