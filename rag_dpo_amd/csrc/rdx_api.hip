@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "k_rows.hpp"
@@ -96,6 +97,7 @@ struct rdx_index {
 
     // scratch (grow-only; never allocated inside a warmed-up search)
     DevBuf r_list, r_q, r_s, r_r, r_c;   // second-chance batch of overflowed queries
+    std::unordered_map<const void*, size_t> func_lds;   // dynamic-LDS limit already raised for a kernel ON THIS DEVICE
     DevBuf sib_scratch, staging, qraw, qhat, qshadow, tau, cntw, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
         o_count, mask, ids;
     hipEvent_t ev[8] = {};
@@ -447,16 +449,23 @@ extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim,
 // ------------------------------------------------------------------------------------------------
 // search
 // ------------------------------------------------------------------------------------------------
+// kernels using more than 64 KiB of dynamic LDS need the limit raised once per kernel and device (the attribute is
+// per device: the cache lives in the index, which is bound to one)
+static int ensure_dynamic_lds(rdx_index* h, const void* func, size_t bytes) {
+    size_t& have = h->func_lds[func];
+    if (have < bytes) {
+        HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return RDX_OK;
+}
+
 template <int BN, int EPI, bool RES, bool SIBT = false>
 static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t st) {
     // LDS: query-image ring (or the whole resident query tile) + BN hit counters + BN thresholds
     const size_t lds = (size_t)(RES ? p.ksteps : RING_SLOTS) * BN * BK * 2 + BN * 8;
     void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES, SIBT> : k_scan<BN, EPI, false, RES, SIBT>;
-    static size_t lds_set[2] = {0, 0};   // per instantiation: raise the dynamic-LDS limit once per size (RES sizes vary with dim)
-    if (lds_set[p.allow ? 1 : 0] < lds) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[p.allow ? 1 : 0] = lds;
-    }
+    RDX_TRY(ensure_dynamic_lds(h, (const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
     HIP_TRY(hipGetLastError());
     return RDX_OK;
@@ -607,11 +616,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             uint32_t list_cap = 1024;
             while (list_cap < (uint32_t)REFINE_LIST && list_cap < 16.0 * exp_hits * n_streams) list_cap *= 2;
             const size_t lds = (size_t)list_cap * 8;
-            static size_t refine_lds = 0;
-            if (refine_lds < lds) {
-                HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                refine_lds = lds;
-            }
+            RDX_TRY(ensure_dynamic_lds(h, (const void*)k_refine, lds));
             hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(256), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
                                list_cap, k, h->two_e(), h->qhat.as<float>(), h->master, h->dim, h->row_base, d_score, d_row, d_count,
                                h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
