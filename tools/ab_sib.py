@@ -6,10 +6,11 @@ from rag_dpo_amd import _lib
 if os.environ.get("RDX_LIB"):
     _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"librdx_{os.environ['RDX_LIB']}.so")
 from rag_dpo_amd import engine, synth
-from oracle import oracle as O
 corpus = synth.make_corpus(40000, 1024); q = synth.make_queries(700, 1024, corpus)
 ix = engine.HipIndex(1024); ix.add(corpus); ix.set_option("force_fast", 1)
-es, er, ec = O.cosine_topk(O.normalize_rows(corpus), q, 10)
+ix.set_option("force_fast", 0); ix.set_option("force_exact", 1)     # reference = the exact full scan of the same library
+es, er, ec = ix.search(q, 10)
+ix.set_option("force_exact", 0); ix.set_option("force_fast", 1)
 for ns in (0, 1):
     ix.set_option("sib_sync", 1 - ns)
     s, r, c = ix.search(q, 10)
