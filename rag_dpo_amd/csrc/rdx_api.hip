@@ -74,6 +74,10 @@ struct DevBuf {
     }
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }   // error paths that return early do not leak scratch
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -85,7 +89,7 @@ struct rdx_index {
     int n_cu = 256;
     int64_t rows = 0, cap = 0;   // cap is a multiple of 256
     float* master = nullptr;     // [cap][dim]
-    _Float16* shadow = nullptr;  // [cap/256][ksteps][256][64]
+    _Float16* shadow = nullptr;  // [cap][dim_pad] fp16 scan copy in MFMA fragment order (rdx_common.hpp corpus_off)
     hipStream_t own_stream = nullptr;
     std::mutex mu;
 
@@ -203,7 +207,8 @@ extern "C" int rdx_index_destroy(rdx_index* h) {
     if (h->master) (void)hipFree(h->master);
     if (h->shadow) (void)hipFree(h->shadow);
     for (DevBuf* b : {&h->staging, &h->qraw, &h->qhat, &h->qshadow, &h->tau, &h->cntw, &h->cand, &h->setmax, &h->exact_list,
-                      &h->iota, &h->dense, &h->ctr, &h->bad, &h->o_score, &h->o_row, &h->o_count, &h->mask, &h->ids})
+                      &h->iota, &h->dense, &h->ctr, &h->bad, &h->o_score, &h->o_row, &h->o_count, &h->mask, &h->ids,
+                      &h->sib_scratch, &h->r_list, &h->r_q, &h->r_s, &h->r_r, &h->r_c})
         b->release();
     if (h->ev_ok)
         for (auto& e : h->ev) (void)hipEventDestroy(e);
@@ -438,7 +443,10 @@ extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim,
         HIP_TRY(hipStreamSynchronize(st));
         if (b) rc = fail(RDX_ERR_INVALID, "embeddings contain NaN or Inf");
     } else {
+        int b = 0;
+        HIP_TRY(hipMemcpyAsync(&b, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));   // scratch below is freed on return
+        if (b) rc = fail(RDX_ERR_INVALID, "embeddings contain NaN or Inf");
     }
     bi.release();
     bo.release();
