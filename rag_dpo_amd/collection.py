@@ -43,7 +43,21 @@ def _default_engine_factory(dim: int, device: int):
     return HipIndex(dim, device)
 
 
-def _as_matrix(embeddings, what: str) -> np.ndarray:
+def _is_device_tensor(x) -> bool:
+    import sys
+    torch = sys.modules.get("torch")
+    return torch is not None and isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def _as_matrix(embeddings, what: str):
+    """-> contiguous fp32 [n][dim]: a numpy array, or the caller's torch CUDA tensor passed through untouched
+    (EmbeddingProvider.embed_device -> add: the batch never becomes Python floats)"""
+    if _is_device_tensor(embeddings):
+        import torch
+        t = embeddings if embeddings.dtype == torch.float32 else embeddings.float()
+        if t.dim() != 2 or t.shape[0] == 0 or t.shape[1] == 0:
+            raise ValueError(f"Expected {what} to be a non-empty [n][dim] tensor, got shape {tuple(t.shape)}")
+        return t.contiguous()
     a = np.asarray(embeddings, dtype=np.float32)
     if a.ndim == 1 and a.size > 0:
         a = a[None, :]
@@ -186,7 +200,7 @@ class Collection:
                 for i in fresh:
                     for v in (metadatas[i] or {}).values():
                         W.kind_of(v)
-            sel = emb if len(fresh) == n else np.ascontiguousarray(emb[fresh])
+            sel = emb if len(fresh) == n else (emb[fresh].contiguous() if _is_device_tensor(emb) else np.ascontiguousarray(emb[fresh]))
             row0 = self._rows
             self._engine.add(sel)   # raises ValueError on NaN/Inf: nothing stored
             self._grow_cols(row0 + len(fresh))
@@ -209,6 +223,8 @@ class Collection:
         ids = list(ids)
         n = len(ids)
         emb = _as_matrix(embeddings, "embeddings") if embeddings is not None else None
+        if _is_device_tensor(emb):
+            emb = emb.cpu().numpy()    # in-place row updates are rare and small: through the host path
         for name, lst in (("embeddings", emb), ("metadatas", metadatas), ("documents", documents)):
             if lst is not None and len(lst) != n:
                 raise ValueError(f"Unequal lengths for fields: ids: {n}, {name}: {len(lst)}")
@@ -239,6 +255,8 @@ class Collection:
             new = [i for i, s in enumerate(ids) if s not in self._row_of]
             pick = lambda lst, idx: None if lst is None else [lst[i] for i in idx]
             emb = _as_matrix(embeddings, "embeddings") if embeddings is not None else None
+            if _is_device_tensor(emb) and old:
+                emb = emb.cpu().numpy()
             if old:
                 self.update([ids[i] for i in old], None if emb is None else emb[old], pick(metadatas, old), pick(documents, old))
             if new:
@@ -325,6 +343,8 @@ class Collection:
         if not isinstance(n_results, (int, np.integer)) or isinstance(n_results, bool) or n_results <= 0:
             raise ValueError(f"Number of requested results {n_results}, cannot be negative, or zero.")
         q = _as_matrix(query_embeddings, "query_embeddings")
+        if _is_device_tensor(q):
+            q = q.cpu().numpy()        # results are Python lists anyway; device callers use HipIndex.search_device
         nq = q.shape[0]
         with self._lock:
             if self._engine is None:   # nothing was ever added
@@ -397,6 +417,8 @@ class Collection:
             return
         rec["n_emb"] = 0 if emb is None else int(emb.shape[0])
         rec["dim"] = None if emb is None else int(emb.shape[1])
+        if _is_device_tensor(emb):
+            emb = emb.cpu().numpy()
         if emb is not None:
             with open(os.path.join(self._dir, "journal.f32"), "ab") as f:
                 f.write(np.ascontiguousarray(emb, dtype=np.float32).tobytes())

@@ -98,9 +98,13 @@ def chunk_metadata(chunk: Dict, url_cache: Optional[Dict[str, str]] = None) -> D
 
 
 class ChromaDBIndexer:
-    def __init__(self, client, embedding_provider, url_cache: Optional[Dict[str, str]] = None):
+    def __init__(self, client, embedding_provider, url_cache: Optional[Dict[str, str]] = None, device_embeddings: bool = False):
+        """device_embeddings=True: batches go `embedding_provider.embed_device(texts)` -> `collection.add(embeddings=<CUDA
+        tensor>)`, i.e. encoder output -> K1 -> HBM without ever becoming Python floats. The default keeps
+        the reference's list-of-lists hand-over."""
         self.chroma_client = client
         self.embedding_provider = embedding_provider
+        self.device_embeddings = device_embeddings and hasattr(embedding_provider, "embed_device")
         self.url_cache = dict(url_cache or {})
         self.collection = None
         self.existing_ids = set()
@@ -146,6 +150,8 @@ class ChromaDBIndexer:
     def generate_embeddings(self, texts: List[str]) -> List[List[float]]:
         """reference :290-298: an embedder failure yields [] and the batch is skipped"""
         try:
+            if self.device_embeddings:
+                return self.embedding_provider.embed_device(texts)
             return self.embedding_provider.embed(texts)
         except Exception as e:   # noqa: BLE001
             logger.error(f"embedding error: {e}")
@@ -159,7 +165,7 @@ class ChromaDBIndexer:
             documents = [chunk_document(c) for c in batch]
             metadatas = [chunk_metadata(c, self.url_cache) for c in batch]
             embeddings = self.generate_embeddings(documents)
-            if not embeddings or len(embeddings) != len(documents):
+            if embeddings is None or len(embeddings) != len(documents):
                 self.stats["errors"] += len(batch)
                 continue
             try:

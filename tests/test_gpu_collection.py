@@ -31,3 +31,36 @@ def test_indexer_flow_gpu(tmp_path):
     indexer left (tests/golden/indexer_golden.json)"""
     from test_indexer_golden import run_reset_then_update
     run_reset_then_update(tmp_path, None)
+
+
+def test_indexer_device_embeddings_route(tmp_path):
+    """ingest with device_embeddings=True (encoder output -> collection.add as a CUDA tensor) leaves the same ids, documents,
+    metadata and neighbours as the reference-style list-of-lists route, survives a reopen through the journal, and the
+    stored rows agree to one rounding of the second normalisation"""
+    import numpy as np
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import indexer_world as IW
+    from rag_dpo_amd import indexer as ix_mod
+    from rag_dpo_amd.collection import PersistentClient
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    prov = EmbeddingProvider(model_name="random-init:tiny", device="cuda").load()
+    chunks = [c for c in IW.base_chunks() if IW.POISON not in c.get("text", "")][:18]
+    cols = []
+    for route, dev in (("lists", False), ("device", True)):
+        client = PersistentClient(path=str(tmp_path / route))
+        ix = ix_mod.ChromaDBIndexer(client, prov, device_embeddings=dev)
+        ix.init_chromadb("reset")
+        ix.index_chunks(chunks, batch_size=5)
+        assert ix.stats["chunks_indexed"] > 0
+        cols.append(ix.collection)
+    a = cols[0].get(include=["documents", "metadatas", "embeddings"])
+    b = cols[1].get(include=["documents", "metadatas", "embeddings"])
+    assert a["ids"] == b["ids"] and a["documents"] == b["documents"] and a["metadatas"] == b["metadatas"]
+    np.testing.assert_allclose(np.asarray(a["embeddings"]), np.asarray(b["embeddings"]), rtol=0, atol=2.5e-7)
+    q = prov.embed(["durée de conservation"])
+    assert cols[0].query(query_embeddings=q, n_results=5)["ids"] == cols[1].query(query_embeddings=q, n_results=5)["ids"]
+    again = PersistentClient(path=str(tmp_path / "device")).get_collection(ix_mod.COLLECTION_NAME)   # journal replay
+    c = again.get(include=["embeddings"])
+    assert c["ids"] == b["ids"]
+    np.testing.assert_allclose(np.asarray(c["embeddings"]), np.asarray(b["embeddings"]), rtol=0, atol=2.5e-7)
