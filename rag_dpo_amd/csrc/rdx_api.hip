@@ -508,9 +508,29 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
     return RDX_OK;
 }
 
+// Host callers: where the results go. They are copied back in front of the search's ONE host synchronisation (the
+// counter read-back); only when that read-back shows that a fallback pass had to rewrite some results are they copied
+// again (HostOut::stale).
+struct HostOut {
+    float* score;
+    int64_t* row;
+    int32_t* count;
+    bool stale;
+};
+
 // depth 0 = the caller's batch; depth 1 = the second-chance batch of queries whose candidate segments overflowed
 static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k, const uint32_t* d_allow, float* d_score,
-                        int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth = 0) {
+                        int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth = 0,
+                        HostOut* ho = nullptr) {
+    auto copy_out = [&]() -> int {
+        if (!ho) return RDX_OK;
+        if (k > 0) {
+            HIP_TRY(hipMemcpyAsync(ho->score, d_score, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(ho->row, d_row, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipMemcpyAsync(ho->count, d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        return RDX_OK;
+    };
     const int nq_pad = (int)((nq + 255) / 256 * 256);
     const bool prof = h->profile != 0 && depth == 0;
     auto mark = [&](int i) {
@@ -551,6 +571,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             HIP_TRY(hipStreamSynchronize(st));
         }
         RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st));
+        RDX_TRY(copy_out());
         HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         n_exact = (int)nq;
@@ -631,9 +652,11 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             HIP_TRY(hipGetLastError());
         }
         mark(5);
+        RDX_TRY(copy_out());
         HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         n_exact = ctr.n_exact;
+        if (n_exact > 0 && ho) ho->stale = true;   // a fallback pass rewrites some of the rows copied above
         if (n_exact > 0 && depth == 0 && h->retry) {
             // Overflow means "far more rows above the sampled threshold than expected": similar rows stored together
             // (chunks of one document) that the sparse sample missed. Before paying the exact full scan (one fp32 pass over
@@ -742,13 +765,14 @@ extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k,
             d_r = h->o_row.as<int64_t>();
             d_c = h->o_count.as<int32_t>();
         }
-        RDX_TRY(search_chunk(h, d_q, m, k, d_allow, d_s, d_r, d_c, st, &s));
-        if (space == RDX_HOST) {
+        HostOut ho = {out_score ? out_score + (size_t)q0 * k : nullptr, out_row ? out_row + (size_t)q0 * k : nullptr, out_count + q0, false};
+        RDX_TRY(search_chunk(h, d_q, m, k, d_allow, d_s, d_r, d_c, st, &s, 0, space == RDX_HOST ? &ho : nullptr));
+        if (space == RDX_HOST && ho.stale) {
             if (k > 0) {
-                HIP_TRY(hipMemcpyAsync(out_score + (size_t)q0 * k, d_s, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipMemcpyAsync(out_row + (size_t)q0 * k, d_r, (size_t)m * k * 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(ho.score, d_s, (size_t)m * k * 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(ho.row, d_r, (size_t)m * k * 8, hipMemcpyDeviceToHost, st));
             }
-            HIP_TRY(hipMemcpyAsync(out_count + q0, d_c, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(ho.count, d_c, (size_t)m * 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
     }
