@@ -86,6 +86,7 @@ class Collection:
         self._cols: Dict[str, W.Column] = {}
         self._lock = threading.RLock()
         self._client = _client
+        self._meta_cache: Dict[int, Optional[dict]] = {}   # row -> metadata dict as last assembled (dropped on any write)
         self._dir: Optional[str] = None        # set by PersistentClient: where the snapshot + journal live
         self._replaying = False
 
@@ -102,6 +103,7 @@ class Collection:
             raise ValueError(f"Embedding dimension {dim} does not match collection dimensionality {self._dim}")
 
     def _set_meta(self, row: int, meta: Optional[dict], replace: bool):
+        self._meta_cache.pop(row, None)
         if replace:
             for col in self._cols.values():
                 col.kind[row] = W.K_MISSING
@@ -122,6 +124,60 @@ class Collection:
             if v is not None:
                 out[k] = v
         return out or None
+
+    _META_CACHE_MAX = 200_000
+
+    def _metas_of(self, rows) -> List[Optional[dict]]:
+        """metadata dicts of the result rows. Rows seen before come out of a per-row cache (a RAG store answers with the
+        same popular chunks again and again; rebuilding 50 dicts of 18 fields from the columns costs more than the GPU
+        search at the reference's corpus size); the caller gets its own copies, as with chromadb."""
+        rows = [int(r) for r in rows]
+        cache = self._meta_cache
+        miss = [r for r in rows if r not in cache]
+        if miss:
+            if len(cache) + len(miss) > self._META_CACHE_MAX:
+                cache.clear()
+            for r, m in zip(miss, self._metas_from_columns(miss)):
+                cache[r] = m
+        return [dict(m) if m else None for m in (cache[r] for r in rows)]
+
+    def _metas_from_columns(self, rows) -> List[Optional[dict]]:
+        """one vectorised gather per column instead of one Column.get per (row, key)"""
+        rr = np.asarray(rows, dtype=np.int64)
+        out: List[dict] = [{} for _ in range(rr.shape[0])]
+        if rr.shape[0] == 0:
+            return []
+        for key, col in self._cols.items():
+            kinds = col.kind[rr]
+            if not kinds.any():
+                continue
+            vocab = col.vocab
+            k0 = int(kinds[0])
+            if k0 != W.K_MISSING and (kinds == k0).all():     # the usual case: one kind for the whole column
+                if k0 == W.K_STR:
+                    vals = [vocab[c] for c in col.code[rr].tolist()]
+                elif k0 == W.K_INT:
+                    vals = col.num[rr].astype(np.int64).tolist()
+                elif k0 == W.K_FLOAT:
+                    vals = col.num[rr].tolist()
+                else:
+                    vals = (col.num[rr] != 0).tolist()
+                for d, v in zip(out, vals):
+                    d[key] = v
+                continue
+            kl = kinds.tolist()
+            nums = col.num[rr].tolist()
+            codes = col.code[rr].tolist()
+            for j, kd in enumerate(kl):
+                if kd == W.K_STR:
+                    out[j][key] = vocab[codes[j]]
+                elif kd == W.K_INT:
+                    out[j][key] = int(nums[j])
+                elif kd == W.K_FLOAT:
+                    out[j][key] = nums[j]
+                elif kd == W.K_BOOL:
+                    out[j][key] = bool(nums[j])
+        return [d or None for d in out]
 
     def _grow_cols(self, n: int):
         for col in self._cols.values():
@@ -159,6 +215,7 @@ class Collection:
         self._alive = np.ones(len(keep), dtype=bool)
         self._row_of = {s: i for i, s in enumerate(self._ids)}
         self._n_dead = 0
+        self._meta_cache.clear()
 
     # ---- chromadb.Collection API ---------------------------------------------------------------
     def count(self) -> int:
@@ -285,6 +342,7 @@ class Collection:
             for r in rows:
                 if self._alive[r]:
                     self._alive[r] = False
+                    self._meta_cache.pop(r, None)
                     self._n_dead += 1
                     del self._row_of[self._ids[r]]
                     self._ids[r] = ""
@@ -316,7 +374,7 @@ class Collection:
                 "ids": [self._ids[r] for r in rows],
                 "embeddings": None,
                 "documents": [self._docs[r] for r in rows] if "documents" in include else None,
-                "metadatas": [self._meta_of(r) for r in rows] if "metadatas" in include else None,
+                "metadatas": self._metas_of(rows) if "metadatas" in include else None,
                 "uris": None,
                 "data": None,
                 "included": include,
@@ -367,7 +425,7 @@ class Collection:
                 if "documents" in include:
                     out_docs.append([self._docs[r] for r in rr])
                 if "metadatas" in include:
-                    out_meta.append([self._meta_of(r) for r in rr])
+                    out_meta.append(self._metas_of(rr))
                 if "distances" in include:
                     out_dist.append([float(x) for x in dist[b, : counts[b]]])
                 if "embeddings" in include:
