@@ -468,11 +468,11 @@ static int ensure_dynamic_lds(rdx_index* h, const void* func, size_t bytes) {
     return RDX_OK;
 }
 
-template <int BN, int EPI, bool RES, bool SIBT = false>
+template <int BN, int EPI, bool RES, bool SIBT = false, bool NTT = false>
 static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t st) {
     // LDS: query-image ring (or the whole resident query tile) + BN hit counters + BN thresholds
     const size_t lds = (size_t)(RES ? p.ksteps : RING_SLOTS) * BN * BK * 2 + BN * 8;
-    void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES, SIBT> : k_scan<BN, EPI, false, RES, SIBT>;
+    void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES, SIBT, NTT> : k_scan<BN, EPI, false, RES, SIBT, NTT>;
     RDX_TRY(ensure_dynamic_lds(h, (const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
     HIP_TRY(hipGetLastError());
@@ -484,6 +484,7 @@ static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, i
     if (bn == 64) return res ? launch_scan<64, EPI, true>(h, p, grid, st) : launch_scan<64, EPI, false>(h, p, grid, st);
     if (bn == 128) return launch_scan<128, EPI, false>(h, p, grid, st);
     if (EPI == EPI_EMIT && p.sib) return launch_scan<256, EPI, false, EPI == EPI_EMIT>(h, p, grid, st);
+    if (p.nqt == 1) return launch_scan<256, EPI, false, false, true>(h, p, grid, st);   // one query tile: corpus read once -> nt loads
     return launch_scan<256, EPI, false>(h, p, grid, st);
 }
 

@@ -86,8 +86,16 @@ struct ScanParams {
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // 16 B per lane straight into VGPRs; completion is the CALLER's business (counted s_waitcnt vmcnt)
+#ifndef RDX_NT_SMALL
+#define RDX_NT_SMALL 1
+#endif
+// NT: the corpus stream of a launch with ONE query tile is read exactly once, by one workgroup -> non-temporal loads (they
+// do not displace the query images in L2 and skip the allocate; measured at 10M x 1024: B = 64 6.3 -> 6.95 TB/s, B = 1
+// 6.3 -> 7.0, B = 128 6.5 -> 6.8). With several query tiles the siblings WANT the tile in L2: plain loads.
+template <bool NT = false>
 __device__ __forceinline__ void gload16(half8& dst, const char* addr) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(addr) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
 }
 
 // all but the N newest vector-memory operations of this wave are complete; the fragments become visible to the compiler
@@ -96,9 +104,10 @@ __device__ __forceinline__ void wait_vmcnt_keep(half8 (&a)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory");
 }
 
-template <int BN, int EPI, bool HAS_MASK, bool RES, bool SIBT = false>
+template <int BN, int EPI, bool HAS_MASK, bool RES, bool SIBT = false, bool NTT = false>
 __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     constexpr int NBN = BN / 32;          // 32-query blocks per wave (a wave owns 32 rows x all BN queries)
+    constexpr bool NT_A = RDX_NT_SMALL && (BN <= 128 || NTT);   // host: BN <= 128 launches and NTT launches have ONE query tile
     constexpr int B_BYTES = BN * BK * 2;  // one k-step image of this workgroup's queries
     constexpr int NPB = BN / 64;          // 1 KiB DMA pieces per wave per query image
     // Sibling lock-step (speed only). The nqt workgroups of a stream read the same corpus tiles; nothing else keeps them
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         {
             const char* s0 = a_src(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) gload16(a0[kk], s0 + kk * 1024);
+            for (int kk = 0; kk < 4; ++kk) gload16<NT_A>(a0[kk], s0 + kk * 1024);
         }
         int it1 = 0, ks1 = 1;
         if (ks1 == KS) { ks1 = 0; it1 = 1; }
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         {
             const char* s1 = a_src(have1 ? it1 : 0, have1 ? ks1 : 0);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) gload16(a1[kk], s1 + kk * 1024);
+            for (int kk = 0; kk < 4; ++kk) gload16<NT_A>(a1[kk], s1 + kk * 1024);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the only barrier that waits for memory: every wave's prologue DMA has landed
@@ -394,13 +403,13 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 #if defined(RDX_ABL_NOA)   // developer ablation (tools/ab_lib.py): timing without the corpus stream, results are garbage
                     asm volatile("" ::"v"(an));
 #elif RDX_MFMA16
-                    gload16(af[2 * kk], an + (2 * kk) * 1024);
-                    gload16(af[2 * kk + 1], an + (2 * kk + 1) * 1024);
+                    gload16<NT_A>(af[2 * kk], an + (2 * kk) * 1024);
+                    gload16<NT_A>(af[2 * kk + 1], an + (2 * kk + 1) * 1024);
                     if constexpr (SIB) {
                         if (kk == 0) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(poll) : "v"(zero_off), "s"(sib_word) : "memory");
                     }
 #else
-                    gload16(af[kk], an + kk * 1024);
+                    gload16<NT_A>(af[kk], an + kk * 1024);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
