@@ -217,44 +217,67 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
     int64_t n_gt;
     const uint32_t kth = block_kth_largest([&](int64_t i) { return f2key(sc[i]); }, rows, kk, hist, bc, &n_gt);
     const int need_eq = (int)(kk - n_gt);   // >= 1
+    constexpr int EQ_CAP = 1024;
+    __shared__ int64_t eq_idx[EQ_CAP];
+    __shared__ int n_eq;
     if (threadIdx.x == 0) {
         n_sel = 0;
         n_eq_taken = 0;
+        n_eq = 0;
     }
     __syncthreads();
-    // entries strictly above the k-th key: any order
+    // ONE more pass: entries strictly above the k-th key go to the list in any order; entries equal to it (normally one)
+    // are collected on the side
     for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) {
         const float v = sc[i];
-        if (f2key(v) > kth) {
+        const uint32_t key = f2key(v);
+        if (key > kth) {
             const int pos = atomicAdd(&n_sel, 1);
             s_s[pos] = v;
             s_r[pos] = row_base + i;
+        } else if (key == kth) {
+            const int e = atomicAdd(&n_eq, 1);
+            if (e < EQ_CAP) eq_idx[e] = i;
         }
     }
     __syncthreads();
-    // entries equal to the k-th key: in ascending row order until need_eq are taken
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int64_t base = 0; base < rows; base += blockDim.x) {
-        if (n_eq_taken >= need_eq) break;   // uniform: read after the barrier below
-        const int64_t i = base + threadIdx.x;
-        const bool eq = i < rows && f2key(sc[i]) == kth;
-        const unsigned long long m = __ballot(eq);
-        if (lane == 0) wave_tot[wave] = __popcll(m);
-        __syncthreads();
-        int before = n_eq_taken;
-        for (int w = 0; w < wave; ++w) before += wave_tot[w];
-        const int my = before + __popcll(m & ((1ull << lane) - 1ull));
-        if (eq && my < need_eq) {
-            s_s[(int)n_gt + my] = sc[i];
-            s_r[(int)n_gt + my] = row_base + i;
+    if (n_eq <= EQ_CAP) {
+        // of the equal entries the need_eq with the LOWEST rows belong to the answer (ties -> ascending row id)
+        const int ne = n_eq;
+        for (int e = threadIdx.x; e < ne; e += blockDim.x) {
+            const int64_t i = eq_idx[e];
+            int rank = 0;
+            for (int f = 0; f < ne; ++f) rank += eq_idx[f] < i;
+            if (rank < need_eq) {
+                s_s[(int)n_gt + rank] = sc[i];
+                s_r[(int)n_gt + rank] = row_base + i;
+            }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int w = 0; w < nw; ++w) t += wave_tot[w];
-            n_eq_taken += t;
+    } else {
+        // thousands of identical scores: walk the rows in order until need_eq equal entries are taken
+        for (int64_t base = 0; base < rows; base += blockDim.x) {
+            if (n_eq_taken >= need_eq) break;   // uniform: read after the barrier below
+            const int64_t i = base + threadIdx.x;
+            const bool eq = i < rows && f2key(sc[i]) == kth;
+            const unsigned long long m = __ballot(eq);
+            if (lane == 0) wave_tot[wave] = __popcll(m);
+            __syncthreads();
+            int before = n_eq_taken;
+            for (int w = 0; w < wave; ++w) before += wave_tot[w];
+            const int my = before + __popcll(m & ((1ull << lane) - 1ull));
+            if (eq && my < need_eq) {
+                s_s[(int)n_gt + my] = sc[i];
+                s_r[(int)n_gt + my] = row_base + i;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int t = 0;
+                for (int w = 0; w < nw; ++w) t += wave_tot[w];
+                n_eq_taken += t;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     __syncthreads();
     // drop -inf (filtered) entries: they sort last, so count the finite prefix after ranking
