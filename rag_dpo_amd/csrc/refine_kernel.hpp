@@ -16,14 +16,14 @@ struct RefineCounters {   // one per index, zeroed before every search
     int bad;              // set by K1 when a query embedding holds NaN/Inf
 };
 
-// One block (256 threads) per query.
+// One block per query (256 threads, 1024 when k is large: the exact re-score runs one wave per candidate row).
 //   The scan left, per (query, stream), cntw hits in a segment of capw slots: (coarse score, row) of every allowed row
 //   whose coarse score >= tau[q]. They are gathered into LDS; c_k = k-th largest coarse score. Every true top-k row has
 //   coarse >= c_k - 2E (|coarse-exact| <= E and k rows reach coarse c_k, hence exact c_k - E), so
 //   P = {coarse >= c_k - 2E} contains the exact top-k; P is re-scored exactly from the fp32 master copy (fp64 lane-order
 //   sum, oracle/rdx_oracle.c) and ranked (score desc, row asc).
 //   A segment, list or P overflow cannot be answered here: the query is flagged for the exact full scan.
-__global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
+__global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
                                                 int n_streams, uint32_t capw, uint32_t list_cap, int k, float two_e,
                                                 const float* __restrict__ qhat, const float* __restrict__ master, int dim,
                                                 int64_t row_base, float* __restrict__ out_score, int64_t* __restrict__ out_row,
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_refine(const uint2* __restrict__ cand, 
     // exact re-score: one wave per candidate row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4* q4 = reinterpret_cast<const float4*>(qhat + (int64_t)q * dim);
-    for (int i = wave; i < p; i += 4) {
+    for (int i = wave; i < p; i += (int)(blockDim.x >> 6)) {
         const float4* row4 = reinterpret_cast<const float4*>(master + s_r[i] * (int64_t)dim);
         const float s = exact_score(row4, q4, dim >> 2, lane);
         if (lane == 0) s_s[i] = s;
