@@ -7,25 +7,31 @@
 // Dataflow (one workgroup = 8 waves = one 256-row corpus tile x BN queries per step, persistent over a stream of tiles):
 //   corpus  HBM --global_load_dwordx4 (1 KiB per wave-instruction, fragment order)--> VGPRs of the ONE wave that owns those
 //           32 rows. No LDS, no sharing between waves, prefetched two k-steps ahead into the registers the matrix pipe
-//           has just finished reading.
-//   queries L2 --LDS-DMA (global_load_lds_dwordx4)--> 3-slot LDS ring of (BN x 64 k) images shared by the 8 waves, filled
-//           two k-steps ahead; when all k-steps of a 64-query tile fit (<= 128 KiB) the tile stays RESIDENT in LDS and
-//           the main loop has no DMA and no barrier at all (the HBM-bound small-batch regime).
-//   MFMA    v_mfma_f32_32x32x16_f16, corpus fragment = A operand, query fragment = B operand: D[row][query] has the QUERY
-//           on the lane (col = lane & 31) and 16 corpus rows in the 16 accumulator registers, so the per-query threshold
-//           lives in one register per lane and the epilogue is compare-only.
+//           has just finished reading. Launches with ONE query tile read every corpus byte once: non-temporal loads.
+//   queries L2 --LDS-DMA (global_load_lds_dwordx4)--> 4-slot LDS ring of (BN x 64 k) images shared by the 8 waves, filled
+//           three k-steps ahead (waves 0..3 right behind the barrier, waves 4..7 a quarter step later: the two waves of
+//           a SIMD never sit in the expensive DMA issue together); when all k-steps of a 64-query tile fit (<= 128 KiB)
+//           the tile stays RESIDENT in LDS and the main loop has no DMA and no barrier at all (the HBM-bound regime).
+//   MFMA    v_mfma_f32_16x16x32_f16 (RDX_MFMA16, default; the 32x32x16 form is kept behind RDX_MFMA16=0), corpus
+//           fragment = A operand, query fragment = B operand: D[row][query] has the QUERY on the lane (col = lane & 15)
+//           and 4 corpus rows in the 4 accumulator registers of a block, so the per-query threshold is one value per
+//           lane and block and the epilogue is compare-only.
 //   The nqt query tiles of one stream run on workgroups with equal blockIdx % 8, i.e. on one XCD, so a corpus tile is
-//   fetched from HBM once and re-read from that XCD's L2 (speed only — nothing depends on the placement).
+//   fetched over the fabric once or twice and otherwise re-read from that XCD's L2 (speed only — nothing depends on
+//   the placement; the optional sibling lock-step below tightens it).
 //
-// Synchronisation per k-step: ONE s_waitcnt vmcnt(V) (V = loads issued during the previous step, which stay in flight)
-// and, in ring mode, ONE s_barrier that never waits for memory: everything a step needs was issued two steps earlier.
+// Synchronisation per k-step: ONE s_waitcnt vmcnt(V) at the top (V = vector-memory operations issued during the previous
+// step, which stay in flight) and, in ring mode, ONE mid-step s_waitcnt + s_barrier that never waits for memory in
+// steady state: everything a step needs was issued two or three steps earlier.
 // The corpus loads are inline asm (the compiler would drain vmcnt(0) at their first use next to LDS-DMA,
 // cdna_hip_programming.md §5 trap (b)); their destination registers are handed to the compiler only through the
-// "+v" operands of the wait statement (§5.7 form (ii)).
+// "+v" operands of the wait statement (§5.7 form (ii)). Consequences the code has to respect: such loads are issued
+// unconditionally (a conditional one makes the compiler copy a register that has not landed), both fragment sets stay
+// alive until the final vmcnt(0), and the kernel must not spill (rag_dpo_amd/build.py refuses a build that does).
 //
 // Epilogues.
-//   EPI_SETMAX (threshold bootstrap, run on every sample_div-th tile): accumulator register positions keep a running max
-//     over all tiles of the stream -> 8 disjoint row sets per (stream, wave) and query. k_tau takes the k-th
+//   EPI_SETMAX (threshold bootstrap, run on every sample_div-th tile): accumulator blocks keep a running max over all
+//     tiles of the stream -> 4 disjoint row sets per (stream, wave) and query, 32 per stream. k_tau takes the k-th
 //     largest set max: k DISTINCT rows score at least that, which makes tau = that - 2E a lower bound for every true
 //     top-k row's coarse score (E = |coarse - exact| bound).
 //   EPI_EMIT (main pass): every (row, query) whose coarse score >= tau[query] is appended to the (query, stream) candidate
