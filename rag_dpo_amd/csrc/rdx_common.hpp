@@ -28,7 +28,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef RDX_MFMA16
 // 1 (default): the scan uses v_mfma_f32_16x16x32_f16; 0: v_mfma_f32_32x32x16_f16. Same cycles per flop, but the chip
 // holds a higher clock on the 16x16x32 shape under this load (MI355X_MICROARCH.md "DVFS give-back" item 7): measured
-// +8 % on the B = 1024 scan (tools/ab_m16.py, same box, interleaved runs). The two shapes want different fragment
+// +4.5 % on the B = 1024 scan end to end (same box, interleaved runs of the two builds). The two shapes want different fragment
 // orders of the corpus scan copy, so the switch is compile-time.
 #define RDX_MFMA16 1
 #endif
@@ -37,7 +37,6 @@ constexpr int TILE_ROWS = 256;                    // corpus rows per scan tile /
 constexpr int BK = 64;                            // k elements per k-step image
 constexpr int KSTEP_BYTES = TILE_ROWS * BK * 2;   // 32 KiB
 constexpr int MAX_DIM = 4096;
-constexpr int SETS_PER_WAVE = 32;                 // threshold-bootstrap sets per (stream, wave row)
 
 // offset (in halfs) of element (row r, column k) inside the fragment-ordered corpus scan copy
 __host__ __device__ inline int64_t corpus_off(int64_t r, int k, int ksteps) {
