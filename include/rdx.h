@@ -85,7 +85,9 @@ int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep);
  * added to every returned row id, so a shard holding rows [base, base+count) answers with GLOBAL ids;
  * "sib_sync" 0/1 (default 0) and "sib_lag" 3..100 (k-steps): soft lock-step of the workgroups that stream
  * the same corpus tiles for different query tiles (less fabric traffic for ~2-3 % of the throughput while the
- * launch is MFMA-bound; speed and traffic only, never results); "retry" 0/1 (default 1): queries whose candidate
+ * launch is MFMA-bound; speed and traffic only, never results); "xcd_balance" 0/1 (default 1): the main scan's
+ * tiles are split between the 8 XCDs by their measured speed in the previous searches instead of evenly (the XCDs of
+ * one chip differ by up to 10 %; speed only); "retry" 0/1 (default 1): queries whose candidate
  * segments overflow get a second MFMA pass as a small batch (denser threshold sample) before the exact full scan. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);
 

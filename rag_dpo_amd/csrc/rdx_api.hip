@@ -94,13 +94,16 @@ struct rdx_index {
     std::mutex mu;
 
     // options
-    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1;
+    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1;
+    double xw[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // relative speed of the XCDs as the last main scans showed it (sum 8)
+    unsigned long long wg_times[1024] = {};    // start/end stamps of the last main scan's workgroups (host copy)
     int sample_div = 64;
     int64_t cand_cap = 0;   // 0 = automatic
     int64_t row_base = 0;   // added to every returned row id (global ids of a shard)
 
     // scratch (grow-only; never allocated inside a warmed-up search)
     DevBuf r_list, r_q, r_s, r_r, r_c;   // second-chance batch of overflowed queries
+    DevBuf wgt;                          // [grid][2] workgroup time stamps of the main scan
     std::unordered_map<const void*, size_t> func_lds;   // dynamic-LDS limit already raised for a kernel ON THIS DEVICE
     DevBuf sib_scratch, staging, qraw, qhat, qshadow, tau, cntw, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
         o_count, mask, ids;
@@ -244,6 +247,10 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "force_fast") h->force_fast = value != 0;
     else if (n == "sib_sync") h->sib_sync = value != 0;
     else if (n == "retry") h->retry = value != 0;
+    else if (n == "xcd_balance") {
+        h->xcd_balance = value != 0;
+        for (double& w : h->xw) w = 1.0;
+    }
     else if (n == "sib_lag") h->sib_lag = (int)std::min<int64_t>(std::max<int64_t>(value, 3), 100);
     else if (n == "profile") h->profile = value != 0;
     else if (n == "sample_div") {
@@ -639,7 +646,26 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         HIP_TRY(hipGetLastError());
         mark(3);
         p.tile_stride = 1;
+        // The eight XCDs do not finish equal shares at the same time (measured on c4: the last XCD 1.1-1.7 ms after the
+        // first of 16.5, always the same ones). Each XCD therefore gets a contiguous range of the tile schedule sized by
+        // its speed in the previous main scans (from the workgroups' own time stamps, damped) — no coordination
+        // inside the kernel, just a different static split. Large launches only.
+        const bool balance = h->xcd_balance && depth == 0 && nqt > 1 && n_tiles >= 1024 && grid <= 512;   // (one query tile = HBM-bound: the interleaved split reads DRAM better, measured)
+        if (balance) {
+            RDX_TRY(h->wgt.ensure((size_t)grid * 16));
+            p.use_xlo = 1;
+            p.wgt = h->wgt.as<unsigned long long>();
+            double acc = 0;
+            for (int x = 0; x <= 8; ++x) {
+                p.xlo[x] = (int)std::llround((double)n_tiles * acc / 8.0);
+                if (x < 8) acc += h->xw[x];
+            }
+            p.xlo[8] = (int)n_tiles;
+        }
         RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, res, p, grid, st));
+        if (balance) HIP_TRY(hipMemcpyAsync(h->wg_times, h->wgt.p, (size_t)grid * 16, hipMemcpyDeviceToHost, st));
+        p.use_xlo = 0;
+        p.wgt = nullptr;
         mark(4);
         {
             // LDS list of the gathered hits: 16x the expected count (heavy-tailed score distributions of structured corpora; a list overflow costs a second pass), at most REFINE_LIST
@@ -658,6 +684,24 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         HIP_TRY(hipStreamSynchronize(st));
         n_exact = ctr.n_exact;
         if (n_exact > 0 && ho) ho->stale = true;   // a fallback pass rewrites some of the rows copied above
+        if (balance) {   // the stamps arrived with the counters: re-weight the XCD shares for the next search
+            unsigned long long t0 = ~0ull, tx[8] = {};
+            for (int b = 0; b < grid; ++b) {
+                t0 = std::min(t0, h->wg_times[2 * b]);
+                tx[b & 7] = std::max(tx[b & 7], h->wg_times[2 * b + 1]);
+            }
+            double dur[8], mean = 0;
+            for (int x = 0; x < 8; ++x) mean += (dur[x] = (double)(tx[x] - t0)) / 8.0;
+            if (mean > 0) {
+                double sum = 0;
+                for (int x = 0; x < 8; ++x) {
+                    h->xw[x] *= std::sqrt(mean / std::max(dur[x], 1.0));   // damped: half the correction per search
+                    h->xw[x] = std::min(1.5, std::max(0.6, h->xw[x]));
+                    sum += h->xw[x];
+                }
+                for (int x = 0; x < 8; ++x) h->xw[x] *= 8.0 / sum;
+            }
+        }
         if (n_exact > 0 && depth == 0 && h->retry) {
             // Overflow means "far more rows above the sampled threshold than expected": similar rows stored together
             // (chunks of one document) that the sparse sample missed. Before paying the exact full scan (one fp32 pass over
