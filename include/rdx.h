@@ -131,6 +131,9 @@ typedef struct rdx_search_stats {
     float ms_normalize, ms_scan_sample, ms_tau, ms_scan_main, ms_refine, ms_exact, ms_total;
     int64_t scan_main_launch_rows, scan_main_launch_queries; /* units of the dominant kernel */
     int64_t retried_queries;  /* queries whose candidate segments overflowed and that got a second MFMA pass */
+    float xcd_finish_spread_ms; /* main scan: last XCD's finish minus first XCD's finish (0 when not measured) */
+    float xcd_share_min, xcd_share_max; /* smallest / largest XCD share of the tiles (1.0 = an eighth) used by that scan */
+    float reserved0;
 } rdx_search_stats;
 int rdx_search_last_stats(rdx_index* h, rdx_search_stats* out);
 

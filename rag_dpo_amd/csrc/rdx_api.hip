@@ -692,6 +692,9 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             }
             double dur[8], mean = 0;
             for (int x = 0; x < 8; ++x) mean += (dur[x] = (double)(tx[x] - t0)) / 8.0;
+            acc_stats->xcd_finish_spread_ms = (float)((*std::max_element(dur, dur + 8) - *std::min_element(dur, dur + 8)) * 1e-5);   // 100 MHz ticks
+            acc_stats->xcd_share_min = (float)*std::min_element(h->xw, h->xw + 8);
+            acc_stats->xcd_share_max = (float)*std::max_element(h->xw, h->xw + 8);
             if (mean > 0) {
                 double sum = 0;
                 for (int x = 0; x < 8; ++x) {
