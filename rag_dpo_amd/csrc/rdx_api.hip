@@ -655,10 +655,17 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             RDX_TRY(h->wgt.ensure((size_t)grid * 16));
             p.use_xlo = 1;
             p.wgt = h->wgt.as<unsigned long long>();
+            // bulk: what the slowest XCD should get, dealt interleaved to everybody (whole iterations of all streams);
+            // tail: the rest, one contiguous range per XCD holding what that XCD should get beyond the bulk
+            const double wmin = *std::min_element(h->xw, h->xw + 8);
+            p.bulk_it = (int)std::max<int64_t>(0, (int64_t)std::floor((double)n_tiles * wmin / 8.0 / G) - 1);
+            const int64_t t0 = (int64_t)p.bulk_it * n_streams, tail = n_tiles - t0;
+            double want[8], sum = 0;
+            for (int x = 0; x < 8; ++x) sum += (want[x] = std::max(0.0, (double)n_tiles * h->xw[x] / 8.0 - (double)p.bulk_it * G));
             double acc = 0;
             for (int x = 0; x <= 8; ++x) {
-                p.xlo[x] = (int)std::llround((double)n_tiles * acc / 8.0);
-                if (x < 8) acc += h->xw[x];
+                p.xlo[x] = (int)(t0 + std::llround((double)tail * (sum > 0 ? acc / sum : x / 8.0)));
+                if (x < 8) acc += want[x];
             }
             p.xlo[8] = (int)n_tiles;
         }

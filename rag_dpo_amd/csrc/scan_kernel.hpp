@@ -85,8 +85,8 @@ struct ScanParams {
     float inv_scale2;          // accumulator -> score
     uint32_t* sib;             // [n_streams][4] progress bytes of the query-tile workgroups of a stream (zeroed per launch), or NULL
     uint8_t* sib_scratch;      // [n_streams][16][8] bytes nobody reads (keeps the per-wave operation counts uniform)
-    int use_xlo;               // main pass: XCD x owns the schedule range [xlo[x], xlo[x+1]) instead of an eighth by striding
-    int xlo[9];                //   (the XCDs of one chip do not run equally fast; the host re-weights the ranges from the
+    int use_xlo, bulk_it;      // main pass: after bulk_it interleaved iterations per stream, XCD x owns the schedule range
+    int xlo[9];                //   [xlo[x], xlo[x+1]) (the XCDs of one chip do not run equally fast; the host sizes the ranges from the
     unsigned long long* wgt;   //   [grid][2] start / end wall_clock64 of every workgroup (NULL: not wanted)   finish times)
     int sib_lag;               // throttle when the slowest sibling looks more than this many k-steps behind (a snapshot is ~2-3 old)
 };
@@ -153,14 +153,18 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 
     const int n_sched = (int)((p.n_tiles + p.tile_stride - 1) / p.tile_stride);   // tiles in this launch
     // schedule entries of this stream: first, first + every, ...   (entry j = corpus tile j * tile_stride)
-    int first = stream, every = n_streams;
     int my_tiles = stream < n_sched ? (n_sched - stream + n_streams - 1) / n_streams : 0;
+    // With use_xlo the schedule has two parts: the first bulk_it iterations of every stream are dealt as above (entries
+    // [0, bulk_it * n_streams), interleaved over all streams: every XCD gets the same), the rest of the schedule is cut
+    // into one contiguous range per XCD, sized by the host so that the faster XCDs take more of it.
+    int tail_first = 0, bulk_it = my_tiles;
     if (p.use_xlo) {
-        const int ls = slot / p.nqt, cnt = p.xlo[xcd + 1] - p.xlo[xcd];   // my stream's index inside the XCD, the XCD's share
-        first = p.xlo[xcd] + ls;
-        every = G;
-        my_tiles = cnt > ls ? (cnt - ls + G - 1) / G : 0;
+        const int ls = slot / p.nqt, cnt = p.xlo[xcd + 1] - p.xlo[xcd];   // my stream's index inside the XCD, the XCD's tail share
+        bulk_it = p.bulk_it;
+        tail_first = p.xlo[xcd] + ls;
+        my_tiles = bulk_it + (cnt > ls ? (cnt - ls + G - 1) / G : 0);
     }
+    auto sched_of = [&](int it_i) { return it_i < bulk_it ? stream + it_i * n_streams : tail_first + (it_i - bulk_it) * G; };
     if (p.wgt && threadIdx.x == 0) p.wgt[2 * blockIdx.x] = wall_clock64();
     const int KS = p.ksteps;
     const int total = my_tiles * KS;   // k-steps of this workgroup (host keeps tiles*ksteps < 2^31)
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     // corpus fragments of (tile iteration it, k-step ks): 4 consecutive 1 KiB chunks of this wave's 32-row block
     const int64_t rb_bytes = (int64_t)KS * 4096;   // bytes of one 32-row block in the scan copy
     auto a_src = [&](int it_i, int ks_i) -> const char* {
-        const int64_t tile = (int64_t)(first + it_i * every) * p.tile_stride;
+        const int64_t tile = (int64_t)sched_of(it_i) * p.tile_stride;
         return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096 + lane * 16;
     };
 
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         };
 
         auto epilogue = [&](int it_done) {
-            const int64_t tile = (int64_t)(first + it_done * every) * p.tile_stride;
+            const int64_t tile = (int64_t)sched_of(it_done) * p.tile_stride;
             const int64_t row_b = tile * TILE_ROWS + wave * 32;   // first row of this wave's 32-row block
             const bool ragged = (tile + 1) * TILE_ROWS > p.rows;  // tile holds padding rows
             uint32_t okbits = 0xffffffffu;                        // bit i: row row_b+i may be used
