@@ -650,7 +650,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         // first of 16.5, always the same ones). Each XCD therefore gets a contiguous range of the tile schedule sized by
         // its speed in the previous main scans (from the workgroups' own time stamps, damped) — no coordination
         // inside the kernel, just a different static split. Large launches only.
-        const bool balance = h->xcd_balance && depth == 0 && nqt > 1 && n_tiles >= 1024 && grid <= 512;   // (one query tile = HBM-bound: the interleaved split reads DRAM better, measured)
+        const bool balance = h->xcd_balance && depth == 0 && n_tiles >= 1024 && grid <= 512;
         if (balance) {
             RDX_TRY(h->wgt.ensure((size_t)grid * 16));
             p.use_xlo = 1;
