@@ -52,13 +52,14 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_shard(shard: HipShard, lo: int, hi: int, dim: int, corpus_kind: str, device):
-    """this rank's rows [lo, hi) of the deterministic synthetic corpus, generated in HBM chunk by chunk"""
+def build_shard(shard: HipShard, lo: int, hi: int, dim: int, corpus_kind: str, device, total_rows: int):
+    """this rank's rows [lo, hi) of the deterministic synthetic corpus of SURVEY.md §8(d) (N(0,1) rows, 1 % exact
+    duplicates), generated in HBM chunk by chunk"""
     shard.index.reserve(hi - lo)
     j0, j1 = lo // synth.CHUNK, (hi + synth.CHUNK - 1) // synth.CHUNK
     for j in range(j0, j1):
         r0 = j * synth.CHUNK
-        rows = synth.torch_corpus_chunk(j, synth.CHUNK, dim, device)
+        rows = synth.torch_corpus_chunk(j, min(synth.CHUNK, total_rows - r0), dim, device)
         a, b = max(lo, r0) - r0, min(hi, r0 + synth.CHUNK) - r0
         rows = rows[a:b].contiguous()
         if corpus_kind == "bf16":
@@ -85,7 +86,7 @@ def effective_cpus() -> int:
     return n
 
 
-def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, total_rows: int):
+def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, total_rows: int, planted=None):
     """rank 0, N=1 only. The oracle is the CHECKER and the timed CPU baseline; never the thing shipped."""
     from oracle import oracle as O
     O.build()
@@ -115,7 +116,7 @@ def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, to
                   f"normalised rows x {bq} queries, best of {reps} ({t_best*1e3:.0f} ms); value = sample QPS x {sample}/{total_rows} rows",
     }
     # --- recall@k vs the exact C oracle on the same bounded sample (GPU restricted to it by the row bitmap)
-    nchk = min(B, 16)
+    nchk = min(B, 64)
     es, er, ec = O.cosine_topk(rows_hat, q[:nchk], k)
     allow = np.zeros(n, dtype=bool)
     allow[:sample] = True
@@ -124,16 +125,57 @@ def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, to
     recall = hits / max(1, int(ec.sum()))
     exact_ids = bool((gr == er).all() and (gc == ec).all())
     max_ds = float(np.abs(gs[:, :k].astype(np.float64) - es.astype(np.float64)).max()) if k else 0.0
-    # --- full-size property: every id the full search returned, re-scored by the oracle, must equal the GPU score
+    # --- full-size properties: (1) every id the full search returned, re-scored by the oracle, equals the GPU score;
+    # (2) the planted queries (q = c_i + 0.3 eps, §8d) find their row first (or an exact duplicate with a lower id);
+    # (3) the exact full scan K5 (fp32, no MFMA, no threshold heuristics; itself oracle-checked at small N) over ALL
+    # rows returns the same ids and score bits as the MFMA path for 16 queries: no better row exists anywhere
     fs, fr, fc = shard.index.search(q[:nchk], k)
     ok_full = True
     for b in range(nchk):
         rr = fr[b, :fc[b]]
         ref = O.scores(shard.index.get(rr), qhat[b])
         ok_full &= bool((ref == fs[b, :fc[b]]).all()) and bool((np.diff(fs[b, :fc[b]].astype(np.float64)) <= 0).all())
+    planted_ok, n_pl = True, 0
+    for qi, ri in planted or []:
+        if qi < nchk and k > 0:
+            n_pl += 1
+            if fr[qi, 0] != ri:
+                a, b_ = shard.index.get(np.array([fr[qi, 0], ri], dtype=np.int64))
+                planted_ok &= bool(fr[qi, 0] < ri and (a == b_).all())
+    nx = min(nchk, 16)
+    shard.index.set_option("force_exact", 1)
+    xs, xr, xc = shard.index.search(q[:nx], k)
+    shard.index.set_option("force_exact", 0)
+    exact_scan_equal = bool((xr == fr[:nx]).all() and (xs == fs[:nx]).all() and (xc == fc[:nx]).all())
     rec = {"value": round(recall, 6), "k": k, "queries": nchk, "sample_rows": sample, "ids_bit_exact": exact_ids,
-           "max_abs_score_diff": max_ds, "full_corpus_returned_scores_match_oracle": ok_full}
+           "max_abs_score_diff": max_ds, "full_corpus_returned_scores_match_oracle": ok_full,
+           "planted_queries_checked": n_pl, "planted_rows_found_first": planted_ok,
+           "full_corpus_exact_scan_queries": nx, "full_corpus_exact_scan_equals_mfma_path": exact_scan_equal}
     return cpu, rec
+
+
+def self_launch(n: int) -> int:
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] launching", " ".join(cmd))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:                       # rank 0 prints exactly one JSON line; anything else goes to stderr
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 or line is not None else 1
 
 
 def main():
@@ -160,9 +202,12 @@ def main():
     rehearsal = os.environ.get("RDX_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: this parent has not touched the GPU (no HIP call so far) and never will;
+        # it starts the N ranks as a CHILD torch.distributed.run (one process per GPU over RCCL), relays rank 0's JSON
+        # line and exits with the child's code. Never an exec from a process that initialised the GPU.
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     device = torch.device("cuda", local_rank)
@@ -185,10 +230,10 @@ def main():
 
     t_build = time.time()
     shard = HipShard(dim, local_rank, row_offset=lo)
-    build_shard(shard, lo, hi, dim, wl["corpus"], device)
+    build_shard(shard, lo, hi, dim, wl["corpus"], device, rows)
     log(f"[rank {rank}] shard rows [{lo}, {hi}) resident in {time.time() - t_build:.1f}s")
     searcher = ShardedSearcher(shard, host_staged=rehearsal)
-    queries = synth.torch_queries(B, dim, device)
+    queries, planted = synth.torch_queries(B, dim, device, total_rows=rows, return_planted=True)   # 10 % planted (§8d)
     shard.index.set_option("profile", 1)    # HIP events around every kernel, on the stream they run on
     for kv in args.set:
         shard.index.set_option(kv.split("=")[0], int(kv.split("=")[1]))
@@ -243,7 +288,7 @@ def main():
         if rank == 0:
             from rag_dpo_amd.engine import HipIndex
             whole = HipShard(dim, local_rank, row_offset=0)
-            build_shard(whole, 0, rows, dim, wl["corpus"], device)
+            build_shard(whole, 0, rows, dim, wl["corpus"], device, rows)
             ws = torch.empty_like(ms_); wr = torch.empty_like(mr_); wc = torch.empty_like(mc_)
             whole.search(queries, k, ws, wr, wc)
             torch.cuda.synchronize(device)
@@ -257,36 +302,55 @@ def main():
         dim_pad = (dim + 63) // 64 * 64
         launch_ms = scan_ms / args.steps
         flops = 2.0 * B * n_local * dim_pad          # algorithmic flop of one main-scan launch
-        bytes_ = n_local * dim_pad * 2.0 + B * dim_pad * 2.0   # fp16 scan copy read once + queries
+        # Two byte counts, both stated: what the launch READS by construction — the fp16 scan copy once +
+        # the fp16 query images — and SURVEY.md §8(d)'s figure for the batch, N_local*d*s + B*d*4 + B*k*8 with s = 4
+        # (fp32 corpus; 2 for the bf16 corpus of config 5): the bytes a scan of the corpus AS DELIVERED would move.
+        bytes_ = n_local * dim_pad * 2.0 + B * dim_pad * 2.0
+        s_in = 2.0 if wl["corpus"] == "bf16" else 4.0
+        bytes_8d = n_local * dim * s_in + B * dim * 4.0 + B * k * 8.0
         t_hbm, t_mfma = bytes_ / (PEAK_HBM_GBS * 1e9), flops / (PEAK_MFMA_TFLOPS * 1e12)
         roof = None
         if stats and stats["path"] == 0 and launch_ms > 0:
-            traffic = None
+            traffic, traffic_src = None, None
             tp = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get(f"{args.workload}_n{world}")
+                    tj = json.load(open(tp))
+                    ent = tj.get(f"{args.workload}_n{world}")
+                    if isinstance(ent, dict):
+                        traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
+                    elif ent is not None:
+                        traffic, traffic_src = ent, tj.get("_source")
                 except Exception:
                     traffic = None
+            sec = launch_ms * 1e-3
             if t_mfma >= t_hbm:
-                ach = flops / (launch_ms * 1e-3) / 1e12
+                ach = flops / sec / 1e12
                 roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(ach / PEAK_MFMA_TFLOPS, 4), "traffic": traffic}
             else:
-                ach = bytes_ / (launch_ms * 1e-3) / 1e9
+                ach = bytes_ / sec / 1e9
                 roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic}
             roof.update({"kernel": "rdx::k_scan<BN,EPI_EMIT> (main scan)", "avg_launch_ms": round(launch_ms, 4),
-                         "launch_rows": n_local, "launch_queries": B,
-                         "hbm_frac_of_8TBs": round(bytes_ / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                         "mfma_frac_of_2.5PF": round(flops / (launch_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)})
+                         "timer": "HIP events recorded by librdx on the stream the kernel is launched on (option profile=1), "
+                                  "averaged over the timed steps of THIS run",
+                         "launch_rows": n_local, "launch_queries": B, "flops_per_launch": flops,
+                         "bytes_read_per_launch": bytes_, "bytes_read_is": "fp16 scan copy once + fp16 query images (what the kernel loads)",
+                         "bytes_survey_8d_per_launch": bytes_8d, "bytes_survey_8d_is": f"N_local*d*{int(s_in)} + B*d*4 + B*k*8 (SURVEY.md §8d)",
+                         "hbm_frac_of_8TBs": round(bytes_ / sec / 1e9 / PEAK_HBM_GBS, 4),
+                         "hbm_frac_of_8TBs_on_survey_8d_bytes": round(bytes_8d / sec / 1e9 / PEAK_HBM_GBS, 4),
+                         "mfma_frac_of_2.5PF": round(flops / sec / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                         "traffic_is": "fabric bytes per launch of this kernel from an EARLIER rocprofv3 --pmc run "
+                                       "(2*FETCH_SIZE + WRITE_SIZE, separate passes), not measured in this run",
+                         "traffic_source": traffic_src})
         # the same corpus swept with a small batch: the HBM-bound regime of the same kernel (BASELINE.json's
         # ">= 50 % of the HBM roofline on the 10M x 1024 scan" is about THIS regime; at B = 1024 the scan is MFMA-bound)
         small = None
         if world == 1 and stats and stats["path"] == 0:
             try:
                 bs = 64
-                qs = synth.torch_queries(bs, dim, device)
+                qs = synth.torch_queries(bs, dim, device, total_rows=rows)
                 for _ in range(2):
                     searcher.search(qs, k)
                 torch.cuda.synchronize(device)
@@ -303,10 +367,41 @@ def main():
                          "frac": round(gbs / PEAK_HBM_GBS, 4)}
             except Exception as e:
                 log(f"small-batch leg failed: {e!r}")
+        # "queries already on device (H2D of B x 4 KB reported separately)". Measured here, never part of
+        # `value`: the H2D copy of the fp32 query batch from pinned host memory, and the whole search called with HOST
+        # pointers (rdx_search RDX_HOST: pageable numpy in, H2D, search, D2H of the k results, numpy out)
+        pcie = None
+        if world == 1 and not encode:
+            try:
+                hq = queries.cpu().pin_memory()
+                dq = torch.empty_like(queries)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                dq.copy_(hq, non_blocking=True)
+                torch.cuda.synchronize(device)
+                e0.record()
+                for _ in range(10):
+                    dq.copy_(hq, non_blocking=True)
+                e1.record()
+                torch.cuda.synchronize(device)
+                h2d_ms = e0.elapsed_time(e1) / 10
+                qn = queries.cpu().numpy()
+                for _ in range(2):
+                    shard.index.search(qn, k)
+                n_h = max(3, min(args.steps, 10))
+                t0h = time.perf_counter()
+                for _ in range(n_h):
+                    shard.index.search(qn, k)
+                wall_h = (time.perf_counter() - t0h) / n_h
+                pcie = {"h2d_queries_ms": round(h2d_ms, 4), "h2d_bytes": int(B * dim * 4),
+                        "h2d_GBps": round(B * dim * 4 / (h2d_ms * 1e-3) / 1e9, 1) if h2d_ms > 0 else None,
+                        "host_pointer_search_ms": round(wall_h * 1e3, 4), "host_pointer_queries_per_s": round(B / wall_h, 1),
+                        "note": "PCIe-inclusive rate (host numpy in -> host numpy out through rdx_search RDX_HOST); reported, never `value`"}
+            except Exception as e:
+                log(f"pcie leg failed: {e!r}")
         cpu, rec = None, None
         if world == 1 and not args.no_cpu:
             try:
-                cpu, rec = cpu_baseline_and_recall(shard, queries, wl, rows)
+                cpu, rec = cpu_baseline_and_recall(shard, queries, wl, rows, planted)
             except Exception as e:   # the checker must never take the measured number down with it
                 log(f"cpu_baseline/recall leg failed: {e!r}")
         out = {
@@ -315,8 +410,10 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16 MFMA scan + f64 exact re-score",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "rows_total": rows, "rows_per_gpu": n_local, "dim": dim,
-                       "batch": B, "k": k, "corpus_dtype": wl["corpus"], "parallelism": f"row-shard x{world} + all-gather merge"},
-            "roofline": roof, "roofline_small_batch": small, "cpu_baseline": cpu, "recall_at_10": rec,
+                       "batch": B, "k": k, "corpus_dtype": wl["corpus"],
+                       "synthetic_inputs": "SURVEY.md §8d: N(0,1) rows with 1 % exact duplicate rows, N(0,1) queries with 10 % planted next to a row",
+                       "parallelism": f"row-shard x{world} + all-gather merge"},
+            "roofline": roof, "roofline_small_batch": small, "pcie_inclusive": pcie, "cpu_baseline": cpu, "recall_at_10": rec,
             "merged_equals_single_index": merged_ok,
             "encode": ({"model": "XLM-R-large (BGE-M3 architecture), random-init fp16, hashing tokenizer", "texts_per_step": B,
                         "avg_ms": round(sum(a.elapsed_time(b) for a, b in enc_ev) / max(1, len(enc_ev)), 3)} if encode else None),

@@ -71,6 +71,11 @@ int rdx_index_add(rdx_index* h, const float* rows, int64_t n, int space);
 /* Config 5 (BASELINE.json): corpus delivered as bf16 (raw 16-bit patterns); the master copy
  * holds the bf16 values widened to fp32 and normalised like any other row. */
 int rdx_index_add_bf16(rdx_index* h, const uint16_t* rows, int64_t n, int space);
+/* Reload of a persisted collection (chromadb's PersistentClient returns stored vectors unchanged, reference app.py:58-59
+ * reads what create_chromadb_index.py wrote): rows are values previously returned by rdx_index_get, i.e. already
+ * L2-normalised; they are stored VERBATIM (no second normalisation, which could move a component by an ulp), so scores
+ * after a reload are bit-identical to those before it. NaN/Inf rows are rejected as in rdx_index_add. */
+int rdx_index_add_stored(rdx_index* h, const float* rows, int64_t n, int space);
 /* `collection.update(ids=, embeddings=)` / upsert: overwrite existing rows in place. */
 int rdx_index_update(rdx_index* h, const int64_t* row_ids, const float* rows, int64_t n, int space);
 /* `collection.get(include=["embeddings"])`: the stored (normalised) fp32 rows. */

@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (plumbing only: device tensors, streams, torch.distributed)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librdx.so")
+# RDX_LIB_PATH: developer override (tools/ab_bench.sh points a run at a variant build WITHOUT touching the product file)
+LIB_PATH = os.environ.get("RDX_LIB_PATH") or os.path.join(_HERE, "librdx.so")
 
 RDX_OK, RDX_ERR_INVALID, RDX_ERR_HIP, RDX_ERR_NOMEM, RDX_ERR_STATE = 0, 1, 2, 3, 4
 RDX_HOST, RDX_DEVICE = 0, 1
@@ -57,6 +58,7 @@ SYMBOLS = {
     "rdx_index_reserve": (_i, [_vp, _i64]),
     "rdx_index_add": (_i, [_vp, _vp, _i64, _i]),
     "rdx_index_add_bf16": (_i, [_vp, _vp, _i64, _i]),
+    "rdx_index_add_stored": (_i, [_vp, _vp, _i64, _i]),
     "rdx_index_update": (_i, [_vp, _vp, _vp, _i64, _i]),
     "rdx_index_get": (_i, [_vp, _vp, _i64, _vp, _i]),
     "rdx_index_compact": (_i, [_vp, _vp, _i64]),

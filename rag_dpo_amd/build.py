@@ -28,12 +28,26 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: librdx needs the ROCm toolchain (/opt/rocm/bin/hipcc)")
 
 
+def source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def is_fresh() -> bool:
+    """the library was built from exactly the sources in the tree (content hash recorded next to it; mtimes alone
+    would accept a variant library copied over the product file)"""
     if not os.path.exists(LIB) or not os.path.exists(RESOURCES):
         return False
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return all(os.path.getmtime(d) <= t for d in deps)
+    try:
+        with open(RESOURCES) as f:
+            rec = json.load(f).get("_build", {})
+    except (OSError, ValueError):
+        return False
+    return rec.get("source_sha256") == source_hash() and rec.get("lib_size") == os.path.getsize(LIB)
 
 
 def parse_resources(remarks: str) -> dict:
@@ -54,7 +68,7 @@ def parse_resources(remarks: str) -> dict:
 
 
 def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and is_fresh():
+    if not force and is_fresh() and not extra_flags:
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage", *extra_flags]
@@ -75,6 +89,7 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str
         raise RuntimeError("scan kernels spill registers — refused (inline-asm loads may be in flight to a spilled register):\n" +
                            "\n".join(f"  {k}: {v}" for k, v in bad.items()))
     os.replace(tmp, LIB)
+    res["_build"] = {"source_sha256": source_hash(), "lib_size": os.path.getsize(LIB), "flags": list(extra_flags)}
     with open(RESOURCES, "w") as f:
         json.dump(res, f, indent=1, sort_keys=True)
     if verbose and diag.strip():

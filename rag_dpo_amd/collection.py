@@ -222,7 +222,7 @@ class Collection:
         with self._lock:
             return self._rows - self._n_dead
 
-    def add(self, ids, embeddings=None, metadatas=None, documents=None, **_ignored):
+    def add(self, ids, embeddings=None, metadatas=None, documents=None, _stored: bool = False, **_ignored):
         """reference create_chromadb_index.py:374-379, ingest_enterprise.py:241-246. Existing ids are skipped
         (chromadb's add never overwrites); duplicate ids inside one call raise DuplicateIDError."""
         if isinstance(ids, str):
@@ -253,13 +253,15 @@ class Collection:
             fresh = [i for i, s in enumerate(ids) if s not in self._row_of]
             if not fresh:
                 return
-            if metadatas is not None:   # validate before anything is stored
+            if metadatas is not None:   # validate EVERYTHING before anything is stored (host and device rows stay in step)
                 for i in fresh:
-                    for v in (metadatas[i] or {}).values():
-                        W.kind_of(v)
+                    W.check_meta(metadatas[i])
             sel = emb if len(fresh) == n else (emb[fresh].contiguous() if _is_device_tensor(emb) else np.ascontiguousarray(emb[fresh]))
             row0 = self._rows
-            self._engine.add(sel)   # raises ValueError on NaN/Inf: nothing stored
+            if _stored:             # snapshot reload: rows are the stored (already normalised) values, kept verbatim
+                self._engine.add_stored(sel)
+            else:
+                self._engine.add(sel)   # raises ValueError on NaN/Inf: nothing stored
             self._grow_cols(row0 + len(fresh))
             for j, i in enumerate(fresh):
                 row = row0 + j
@@ -285,6 +287,9 @@ class Collection:
         for name, lst in (("embeddings", emb), ("metadatas", metadatas), ("documents", documents)):
             if lst is not None and len(lst) != n:
                 raise ValueError(f"Unequal lengths for fields: ids: {n}, {name}: {len(lst)}")
+        if metadatas is not None:
+            for m in metadatas:
+                W.check_meta(m)
         with self._lock:
             hit = [(i, self._row_of[s]) for i, s in enumerate(ids) if s in self._row_of]
             if emb is not None and hit:
@@ -454,54 +459,90 @@ class Collection:
                 self._write_header(self._dir, self._snap_rows)
 
     # ---- persistence: own shard format ------------------------------------------
-    # <dir>/collection.json        name, metadata, dim, rows of the snapshot
-    # <dir>/embeddings.f32.npy     snapshot: normalised fp32 rows, in row order
-    # <dir>/records.jsonl          snapshot: one {"id", "document", "metadata"} per row
-    # <dir>/journal.jsonl + .f32   every add/update/delete since the snapshot, appended when the call returns (chromadb's
-    #                              PersistentClient is durable per call and the reference never calls persist():
-    #                              create_chromadb_index.py writes, app.py reads in another process). persist() folds
-    #                              the journal into a new snapshot.
+    # <dir>/collection.json              name, metadata, dim, rows and GENERATION g of the current snapshot (format 3)
+    # <dir>/snap<g>.embeddings.f32.npy   snapshot: the stored (normalised) fp32 rows, in row order; reloaded VERBATIM
+    # <dir>/snap<g>.records.jsonl        snapshot: one {"id", "document", "metadata"} per row
+    # <dir>/journal<g>.jsonl + .f32      every add/update/delete since snapshot g, appended (and fsync'ed) before the call
+    #                                    returns: chromadb's PersistentClient is durable per call and the reference never
+    #                                    calls persist() (create_chromadb_index.py writes, app.py reads in another process).
+    # Crash consistency. A journal record is committed by its complete jsonl line, written AFTER its vectors; the line
+    # carries the byte range of those vectors in journal.f32, so orphan floats of a writer killed between the two writes
+    # are never read, and opening a store truncates both files to the last committed record (a torn last line, or floats
+    # without a line, vanish). persist() writes snapshot g+1 under new names, then replaces collection.json atomically
+    # (the commit point: it names the generation), then deletes generation g — a crash at any point leaves either g or
+    # g+1 complete, and the files of the other one are removed at the next open.
     _snap_rows = 0
+    _gen = 0
+
+    def _names(self, gen: Optional[int]):
+        pre = "" if gen is None else f"snap{gen}."
+        jp = "journal" if gen is None else f"journal{gen}"
+        return {"emb": pre + "embeddings.f32.npy", "rec": pre + "records.jsonl", "jl": jp + ".jsonl", "jf": jp + ".f32"}
+
+    def _cur_names(self):
+        return self._names(self._gen if self._snap_format >= 3 else None)   # format 2 stores (round 1) had one unnamed generation
 
     def _write_header(self, path: str, rows: int):
         os.makedirs(path, exist_ok=True)
         tmp = os.path.join(path, "collection.json.tmp")
         with open(tmp, "w", encoding="utf-8") as f:
-            json.dump({"name": self.name, "metadata": self.metadata, "dim": self._dim, "rows": rows, "format": 2}, f)
+            json.dump({"name": self.name, "metadata": self.metadata, "dim": self._dim, "rows": rows,
+                       "format": self._snap_format, "gen": self._gen}, f)
+            f.flush()
+            os.fsync(f.fileno())
         os.replace(tmp, os.path.join(path, "collection.json"))
 
-    def _log(self, rec: dict, emb: Optional[np.ndarray]):
+    def _log(self, rec: dict, emb):
         if not self._dir or self._replaying:
             return
+        nm = self._cur_names()
         rec["n_emb"] = 0 if emb is None else int(emb.shape[0])
         rec["dim"] = None if emb is None else int(emb.shape[1])
         if _is_device_tensor(emb):
             emb = emb.cpu().numpy()
         if emb is not None:
-            with open(os.path.join(self._dir, "journal.f32"), "ab") as f:
-                f.write(np.ascontiguousarray(emb, dtype=np.float32).tobytes())
-        with open(os.path.join(self._dir, "journal.jsonl"), "a", encoding="utf-8") as f:   # the line commits the op
+            raw = np.ascontiguousarray(emb, dtype=np.float32).tobytes()
+            with open(os.path.join(self._dir, nm["jf"]), "ab") as f:
+                rec["f32_off"] = f.seek(0, os.SEEK_END)
+                rec["f32_len"] = len(raw)
+                f.write(raw)
+                f.flush()
+                os.fsync(f.fileno())
+        with open(os.path.join(self._dir, nm["jl"]), "a", encoding="utf-8") as f:   # the complete line commits the op
             f.write(json.dumps(rec, ensure_ascii=False) + "\n")
+            f.flush()
+            os.fsync(f.fileno())
 
     def _save(self, path: str):
         with self._lock:
             if self._n_dead:
                 self._compact()
             os.makedirs(path, exist_ok=True)
+            old = self._cur_names()
+            self._snap_format = 3
+            self._gen += 1
+            nm = self._names(self._gen)
             n = self._rows
             if n:
-                emb = self._engine.get(np.arange(n, dtype=np.int64))   # normalised fp32 rows
-                np.save(os.path.join(path, "embeddings.f32.npy"), emb)
-            with open(os.path.join(path, "records.jsonl"), "w", encoding="utf-8") as f:
+                emb = self._engine.get(np.arange(n, dtype=np.int64))   # the stored (normalised) fp32 rows
+                with open(os.path.join(path, nm["emb"]), "wb") as f:
+                    np.save(f, emb)
+                    f.flush()
+                    os.fsync(f.fileno())
+            with open(os.path.join(path, nm["rec"]), "w", encoding="utf-8") as f:
                 for r in range(n):
                     f.write(json.dumps({"id": self._ids[r], "document": self._docs[r], "metadata": self._meta_of(r)},
                                        ensure_ascii=False) + "\n")
-            self._write_header(path, n)
+                f.flush()
+                os.fsync(f.fileno())
+            self._write_header(path, n)          # commit point: the header names generation g+1
             self._snap_rows = n
-            for fn in ("journal.jsonl", "journal.f32"):
+            for fn in old.values():
                 fp = os.path.join(path, fn)
                 if os.path.exists(fp):
                     os.remove(fp)
+
+    _snap_format = 3
 
     def _load(self, path: str):
         with open(os.path.join(path, "collection.json"), encoding="utf-8") as f:
@@ -509,12 +550,21 @@ class Collection:
         self.metadata = meta.get("metadata") or {}
         n = int(meta.get("rows", 0))
         self._snap_rows = n
+        self._snap_format = int(meta.get("format", 2))
+        self._gen = int(meta.get("gen", 0))
+        nm = self._cur_names()
+        # files of another generation: a persist() that was killed before or after its commit point
+        keep = set(nm.values()) | {"collection.json"}
+        for fn in os.listdir(path):
+            if fn not in keep and (fn.startswith("snap") or fn.startswith("journal") or fn == "collection.json.tmp"
+                                   or (self._snap_format >= 3 and fn in self._names(None).values())):
+                os.remove(os.path.join(path, fn))
         self._replaying = True
         try:
             if n:
-                emb = np.load(os.path.join(path, "embeddings.f32.npy"), mmap_mode="r", allow_pickle=False)
+                emb = np.load(os.path.join(path, nm["emb"]), mmap_mode="r", allow_pickle=False)
                 ids, docs, metas = [], [], []
-                with open(os.path.join(path, "records.jsonl"), encoding="utf-8") as f:
+                with open(os.path.join(path, nm["rec"]), encoding="utf-8") as f:
                     for line in f:
                         rec = json.loads(line)
                         ids.append(rec["id"])
@@ -523,29 +573,46 @@ class Collection:
                 step = 65536
                 for a in range(0, n, step):
                     b = min(n, a + step)
-                    self.add(ids=ids[a:b], embeddings=np.asarray(emb[a:b]), documents=docs[a:b], metadatas=metas[a:b])
-            jp = os.path.join(path, "journal.jsonl")
+                    self.add(ids=ids[a:b], embeddings=np.asarray(emb[a:b]), documents=docs[a:b], metadatas=metas[a:b],
+                             _stored=True)   # verbatim: scores after a reload are bit-identical to those before
+            jp, fp = os.path.join(path, nm["jl"]), os.path.join(path, nm["jf"])
             if os.path.exists(jp):
-                fp = os.path.join(path, "journal.f32")
-                raw = np.memmap(fp, dtype=np.float32, mode="r") if os.path.exists(fp) and os.path.getsize(fp) else None
-                pos = 0
-                with open(jp, encoding="utf-8") as f:
-                    for line in f:
-                        try:
-                            rec = json.loads(line)
-                        except ValueError:      # torn last line of a killed writer: the op never committed
-                            break
-                        emb = None
-                        if rec.get("n_emb"):
-                            cnt = rec["n_emb"] * rec["dim"]
-                            emb = np.array(raw[pos: pos + cnt]).reshape(rec["n_emb"], rec["dim"])
-                            pos += cnt
-                        if rec["op"] == "add":
-                            self.add(ids=rec["ids"], embeddings=emb, documents=rec["documents"], metadatas=rec["metadatas"])
-                        elif rec["op"] == "update":
-                            self.update(ids=rec["ids"], embeddings=emb, documents=rec["documents"], metadatas=rec["metadatas"])
-                        elif rec["op"] == "delete":
-                            self.delete(ids=rec["ids"])
+                with open(jp, "rb") as f:
+                    blob = f.read()
+                f32_size = os.path.getsize(fp) if os.path.exists(fp) else 0
+                raw = np.memmap(fp, dtype=np.uint8, mode="r") if f32_size else None
+                good, f32_end, pos, legacy_pos = 0, 0, 0, 0
+                while pos < len(blob):
+                    nl = blob.find(b"\n", pos)
+                    if nl < 0:
+                        break                      # torn last line of a killed writer: the op never committed
+                    try:
+                        rec = json.loads(blob[pos:nl].decode("utf-8"))
+                    except ValueError:
+                        break
+                    emb = None
+                    if rec.get("n_emb"):
+                        cnt = rec["n_emb"] * rec["dim"] * 4
+                        off = rec.get("f32_off", legacy_pos)      # format 2 journals carry no offsets: running position
+                        if off + cnt > f32_size:
+                            break                  # its vectors never reached the disk: not committed
+                        emb = np.frombuffer(raw[off: off + cnt].tobytes(), dtype=np.float32).reshape(rec["n_emb"], rec["dim"])
+                        legacy_pos = off + cnt
+                        f32_end = max(f32_end, off + cnt)
+                    if rec["op"] == "add":
+                        self.add(ids=rec["ids"], embeddings=emb, documents=rec["documents"], metadatas=rec["metadatas"])
+                    elif rec["op"] == "update":
+                        self.update(ids=rec["ids"], embeddings=emb, documents=rec["documents"], metadatas=rec["metadatas"])
+                    elif rec["op"] == "delete":
+                        self.delete(ids=rec["ids"])
+                    pos = good = nl + 1
+                del raw
+                if good < len(blob):               # drop the torn tail so that the next record starts on a fresh line
+                    with open(jp, "r+b") as f:
+                        f.truncate(good)
+                if f32_size > f32_end:             # drop orphan vectors of an uncommitted record
+                    with open(fp, "r+b") as f:
+                        f.truncate(f32_end)
         finally:
             self._replaying = False
 
@@ -599,10 +666,9 @@ class PersistentClient:
         if self.path:
             d = os.path.join(self.path, name)
             if os.path.isdir(d):
-                for fn in ("collection.json", "records.jsonl", "embeddings.f32.npy", "journal.jsonl", "journal.f32"):
-                    fp = os.path.join(d, fn)
-                    if os.path.exists(fp):
-                        os.remove(fp)
+                for fn in os.listdir(d):
+                    if fn.startswith(("collection.json", "snap", "journal", "records.jsonl", "embeddings.f32.npy")):
+                        os.remove(os.path.join(d, fn))
                 try:
                     os.rmdir(d)
                 except OSError:

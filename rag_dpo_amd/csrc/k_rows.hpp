@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
                                                    int64_t n, int dim, const int64_t* __restrict__ dst_rows,
                                                    int64_t row0, float* __restrict__ master,
                                                    _Float16* __restrict__ shadow, int ksteps, float scale,
-                                                   int* __restrict__ bad, int64_t n_pad = 0) {
+                                                   int* __restrict__ bad, int64_t n_pad = 0, int verbatim = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if constexpr (QUERY) {
@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
     }
     double den = sqrt(n2);
     if (den < 1e-12) den = 1e-12;
+    if (verbatim) den = 1.0;   // rows that ARE stored values (snapshot reload): x / 1.0 == x, kept bit for bit
     const int64_t dst = dst_rows ? dst_rows[i] : row0 + i;
     for (int g = lane; g < n4; g += 64) {
         const float4 v = load4(g);

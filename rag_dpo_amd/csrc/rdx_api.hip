@@ -273,7 +273,8 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
 static const int64_t STAGE_ROWS = 32768;
 
 // normalise n rows (host or device, fp32 or bf16) into master/shadow at dst rows (row0.. or dst_ids)
-static int ingest(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int space, int64_t row0, const int64_t* d_dst_ids) {
+static int ingest(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int space, int64_t row0, const int64_t* d_dst_ids,
+                  bool verbatim = false) {
     hipStream_t st = h->own_stream;
     if (space == RDX_DEVICE) HIP_TRY(hipDeviceSynchronize());   // the caller's producers of `rows` (any stream) are done
     const size_t esz = is_bf16 ? 2 : 4;
@@ -291,7 +292,7 @@ static int ingest(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int s
         const int grid = (int)((m + 3) / 4);
         hipLaunchKernelGGL(k_normalize<false>, dim3(grid), dim3(256), 0, st, is_bf16 ? nullptr : (const float*)src,
                            is_bf16 ? (const uint16_t*)src : nullptr, m, h->dim, d_dst_ids ? d_dst_ids + off : nullptr,
-                           row0 + off, h->master, h->shadow, h->ksteps, h->scale(), h->bad.as<int>());
+                           row0 + off, h->master, h->shadow, h->ksteps, h->scale(), h->bad.as<int>(), (int64_t)0, verbatim ? 1 : 0);
         HIP_TRY(hipGetLastError());
         if (space == RDX_HOST) HIP_TRY(hipStreamSynchronize(st));   // staging is reused by the next chunk
     }
@@ -302,14 +303,14 @@ static int ingest(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int s
     return RDX_OK;
 }
 
-static int add_impl(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int space) {
+static int add_impl(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int space, bool verbatim = false) {
     if (!h || (n > 0 && !rows) || n < 0) return fail(RDX_ERR_INVALID, "rdx_index_add: bad argument");
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (n == 0) return RDX_OK;
     std::lock_guard<std::mutex> lk(h->mu);
     RDX_TRY(set_device(h));
     RDX_TRY(grow(h, h->rows + n));
-    RDX_TRY(ingest(h, rows, is_bf16, n, space, h->rows, nullptr));
+    RDX_TRY(ingest(h, rows, is_bf16, n, space, h->rows, nullptr, verbatim));
     h->rows += n;
     return RDX_OK;
 }
@@ -317,6 +318,9 @@ static int add_impl(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int
 extern "C" int rdx_index_add(rdx_index* h, const float* rows, int64_t n, int space) { return add_impl(h, rows, false, n, space); }
 extern "C" int rdx_index_add_bf16(rdx_index* h, const uint16_t* rows, int64_t n, int space) {
     return add_impl(h, rows, true, n, space);
+}
+extern "C" int rdx_index_add_stored(rdx_index* h, const float* rows, int64_t n, int space) {
+    return add_impl(h, rows, false, n, space, true);
 }
 
 // copy a host or device int64 id list to the device scratch `ids`, validating on the host when possible
@@ -694,6 +698,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         if (balance) {   // the stamps arrived with the counters: re-weight the XCD shares for the next search
             unsigned long long t0 = ~0ull, tx[8] = {};
             for (int b = 0; b < grid; ++b) {
+                if ((b >> 3) >= G * nqt) continue;   // idle workgroups (wpx % nqt != 0) return before they stamp
                 t0 = std::min(t0, h->wg_times[2 * b]);
                 tx[b & 7] = std::max(tx[b & 7], h->wg_times[2 * b + 1]);
             }

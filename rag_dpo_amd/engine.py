@@ -73,6 +73,11 @@ class HipIndex:
         p, n, space, keep = self._rows_arg(rows)
         L.check(self._lib.rdx_index_add(self._h, p, n, space))
 
+    def add_stored(self, rows):
+        """rows previously returned by get() (already normalised): stored verbatim (snapshot reload)"""
+        p, n, space, keep = self._rows_arg(rows)
+        L.check(self._lib.rdx_index_add_stored(self._h, p, n, space))
+
     def add_bf16(self, rows):
         p, n, space, keep = self._rows_arg(rows, dtype=np.uint16)
         L.check(self._lib.rdx_index_add_bf16(self._h, p, n, space))

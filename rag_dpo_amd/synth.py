@@ -45,18 +45,52 @@ def make_queries(b: int, dim: int = 1024, corpus: np.ndarray | None = None) -> n
     return q
 
 
-def torch_corpus_chunk(j: int, rows: int, dim: int, device):
+def torch_corpus_chunk(j: int, rows: int, dim: int, device, duplicates: bool = True):
+    """chunk j of the bench-size corpus, generated in HBM: `rows` N(0,1) rows from seed (1234, j); 1 % of them are then
+    overwritten with exact copies of other rows OF THE SAME CHUNK (the tie rule at bench size), so any
+    shard can still be regenerated chunk by chunk without its neighbours"""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(1234 * 1000003 + j)
-    return torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32)
+    out = torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32)
+    if duplicates and rows >= 200:
+        n_dup = rows // 100
+        dst = torch.randperm(rows, generator=g, device=device)[:n_dup]
+        src = torch.randint(0, rows, (n_dup,), generator=g, device=device)
+        out[dst] = out[src]          # advanced indexing reads the pre-assignment values
+    return out
 
 
-def torch_queries(b: int, dim: int, device):
+def torch_corpus_row(i: int, total_rows: int, dim: int, device):
+    """raw row i of the bench corpus as build_shard stores it (whole chunk regenerated: ~1 ms on the GPU)"""
+    j = i // CHUNK
+    return torch_corpus_chunk(j, min(CHUNK, total_rows - j * CHUNK), dim, device)[i % CHUNK].clone()
+
+
+def torch_queries(b: int, dim: int, device, total_rows: int = 0, return_planted: bool = False):
+    """b N(0,1) queries from seed 4321; with total_rows > 0, 10 % of them are planted next to a corpus row:
+    q = c_i/|c_i| + 0.3 * eps/sqrt(dim) — identical on every rank (each regenerates the rows it needs)"""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(4321)
-    return torch.randn((b, dim), generator=g, device=device, dtype=torch.float32)
+    q = torch.randn((b, dim), generator=g, device=device, dtype=torch.float32)
+    planted = []
+    if total_rows > 0 and b >= 10:
+        n_plant = b // 10
+        which = torch.randperm(b, generator=g, device=device)[:n_plant].tolist()
+        rows = torch.randint(0, total_rows, (n_plant,), generator=g, device=device).tolist()
+        eps = torch.randn((n_plant, dim), generator=g, device=device, dtype=torch.float32)
+        cache = {}
+        for t, (qi, ri) in enumerate(zip(which, rows)):
+            j = ri // CHUNK
+            if j not in cache:
+                cache.clear()        # one chunk (268 MB at d = 1024) at a time
+                cache[j] = torch_corpus_chunk(j, min(CHUNK, total_rows - j * CHUNK), dim, device)
+            c = cache[j][ri % CHUNK]
+            q[qi] = c / c.norm() + 0.3 * eps[t] / (dim ** 0.5)
+            planted.append((qi, ri))
+        cache.clear()
+    return (q, planted) if return_planted else q
 
 
 _WORDS = ("durée conservation données personnelles traitement registre sous-traitant responsable AIPD analyse impact consentement "

@@ -32,6 +32,23 @@ def kind_of(v: Any) -> int:
     raise ValueError(f"metadata values must be str, int, float or bool, got {type(v).__name__}: {v!r}")
 
 
+def check_meta(meta: Optional[dict]):
+    """everything Column.set could object to, checked BEFORE anything is stored (so that a bad value in the middle of a
+    batch cannot leave the host rows and the device rows of a collection out of step)"""
+    if not meta:
+        return
+    for k, v in meta.items():
+        if not isinstance(k, str):
+            raise ValueError(f"Expected metadata key to be a str, got {k!r}")
+        if v is None:
+            continue
+        kd = kind_of(v)
+        if kd == K_INT and abs(int(v)) >= 2 ** 53:
+            raise ValueError("integer metadata beyond 2^53 is not supported")
+        if kd != K_STR:
+            float(v)
+
+
 class Column:
     """One metadata key over all rows: a kind tag per row + typed storage (strings dictionary-coded)."""
 

@@ -26,6 +26,9 @@ class OracleEngine:
     def add(self, x):
         self.rows = np.concatenate([self.rows, O.normalize_rows(self._check(x))])
 
+    def add_stored(self, x):
+        self.rows = np.concatenate([self.rows, self._check(x)])
+
     def update(self, ids, x):
         self.rows[np.asarray(ids, dtype=np.int64)] = O.normalize_rows(self._check(x))
 

@@ -49,6 +49,7 @@ def test_scan_kernels_do_not_spill():
     from rag_dpo_amd import build
     build.build_lib()
     res = json.load(open(build.RESOURCES))
+    assert res["_build"]["source_sha256"] == build.source_hash()
     scans = {k: v for k, v in res.items() if "k_scan" in k}
     assert len(scans) >= 16, sorted(scans)
     for k, v in scans.items():

@@ -8,6 +8,11 @@ checked through properties that do not need a CPU pass over the whole corpus:
   partition    searching the two halves of the corpus separately (row bitmaps) and merging the partial lists with
                rdx_merge_topk gives the full search again, bit for bit (what the multi-GPU path relies on)
   sample       restricted by the row bitmap to 128K rows, ids and scores equal the oracle's exact top-k of those rows
+  full scan    the exact full scan K5 (fp32 master, fp64 lane-order sums, no MFMA, no threshold heuristics; itself checked
+               against the oracle at small N in test_gpu_parity.py) over ALL rows returns the same ids and score bits as
+               the MFMA path for 32 queries: no better row exists anywhere in the corpus
+
+The corpus and the queries follow SURVEY.md §8(d): 1 % exact duplicate rows, 10 % of the queries planted next to a row.
 
 The oracle is only the checker here. ~41 GB + 20 GB of HBM at 10M rows."""
 import numpy as np
@@ -36,7 +41,8 @@ def test_full_size_properties(rows, b, k, oracle):
     ix = _build(eng, rows, dim)
     assert len(ix) == rows
     rng = np.random.default_rng(7)
-    q = synth.torch_queries(b, dim, "cuda:0").cpu().numpy()
+    q, planted = synth.torch_queries(b, dim, "cuda:0", total_rows=rows, return_planted=True)
+    q = q.cpu().numpy()
     # known answers: query 0..7 ARE stored rows (taken back out of the index), query 8..15 are planted next to rows
     known = rng.integers(0, rows, size=16)
     stored = ix.get(known)
@@ -62,6 +68,23 @@ def test_full_size_properties(rows, b, k, oracle):
         assert (first == stored[i]).all(), i          # the row itself, or an identical row with a lower id
         assert r[i, 0] <= known[i]
     assert (s[:8, 0] > 0.999999).all()
+    # §8(d) planted queries (q = c_i + 0.3 eps): the row comes back first, or an exact duplicate of it with a lower id
+    for qi, ri in planted:
+        if qi >= 16:
+            if r[qi, 0] != ri:
+                a, b_ = ix.get(np.array([r[qi, 0], ri]))
+                assert r[qi, 0] < ri and (a == b_).all(), (qi, ri, r[qi, 0])
+    # full scan: K5 over all rows == the MFMA path, for the known-answer queries, planted ones and plain random ones
+    nx = 32
+    pick = np.array(list(range(16)) + [qi for qi, _ in planted if qi >= 16][:8], dtype=np.int64)
+    pick = np.concatenate([pick, np.setdiff1d(np.arange(16, b), pick)[: nx - len(pick)]])
+    ix.set_option("force_exact", 1)
+    xs, xr, xc = ix.search(q[pick], k)
+    assert ix.last_stats()["path"] == 1
+    ix.set_option("force_exact", 0)
+    np.testing.assert_array_equal(xr, r[pick])
+    np.testing.assert_array_equal(xs, s[pick])
+    np.testing.assert_array_equal(xc, c[pick])
     # partition: two halves by bitmap, merged = full
     nchk = 32
     half = np.zeros(rows, dtype=bool)

@@ -70,6 +70,17 @@ def test_fast_path_parity(eng, oracle, n, b, k):
     assert st["emitted"] >= b * k
 
 
+def test_baseline_config2(eng, oracle):
+    """BASELINE.json config 2 as written: 100k x 1024 fp32, batch 64, top-10 — the whole corpus against the oracle
+    (ids and score bits), default path selection (MFMA scan, LDS-resident 64-query tile), §8(d) inputs"""
+    corpus = synth.make_corpus(100_000, 1024)
+    q = synth.make_queries(64, 1024, corpus)
+    ix = _index(eng, corpus)
+    st = _check(oracle, ix, corpus, q, 10, expect_path=0)
+    assert st["exact_queries"] == 0, st
+    ix.close()
+
+
 def test_fast_path_other_dims(eng, oracle):
     rng = np.random.default_rng(11)
     for d in (768, 200, 64):
