@@ -195,3 +195,131 @@ def test_import_collection_pages_through_a_chroma_shaped_source(tmp_path, factor
     assert src.query(query_embeddings=q, n_results=7)["ids"] == dst.query(query_embeddings=q, n_results=7)["ids"]
     again = PersistentClient(path=str(tmp_path / "db"), engine_factory=factory).get_collection("rag_dpo_chunks")
     assert again.get(include=[])["ids"] == a["ids"]
+
+
+# ---- crash consistency of the persisted store (journal + snapshot generations) ---------------------------------
+
+def _open(tmp_path):
+    return PersistentClient(path=str(tmp_path / "db"), engine_factory=oracle_factory)
+
+
+def _state(col):
+    g = col.get(include=["documents", "metadatas", "embeddings"])
+    return g["ids"], g["documents"], g["metadatas"], np.asarray(g["embeddings"])
+
+
+def test_journal_survives_a_kill_between_its_two_writes(tmp_path):
+    """a writer killed after the vectors of an op reached journal.f32 but before its jsonl line: the orphan floats must
+    not shift the vectors of later ops (each record names its own byte range) and vanish at the next open"""
+    import os
+    cl = _open(tmp_path)
+    col = cl.create_collection("rag_dpo_chunks", metadata={"hnsw:space": "cosine"})
+    emb = synth.make_corpus(40, 64)
+    col.add(ids=[f"a{i}" for i in range(10)], embeddings=emb[:10].tolist(), documents=[f"d{i}" for i in range(10)])
+    d = col._dir
+    jf = os.path.join(d, col._cur_names()["jf"])
+    committed = os.path.getsize(jf)
+    with open(jf, "ab") as f:                       # the killed writer's vectors: 7 rows that never got their line
+        f.write(np.full((7, 64), 123.0, dtype=np.float32).tobytes())
+    cl2 = _open(tmp_path)                           # next process: opens, appends its own op
+    col2 = cl2.get_collection("rag_dpo_chunks")
+    assert col2.count() == 10 and os.path.getsize(jf) == committed        # orphan floats truncated away
+    col2.add(ids=[f"b{i}" for i in range(5)], embeddings=emb[10:15].tolist())
+    col3 = _open(tmp_path).get_collection("rag_dpo_chunks")
+    ids, _, _, e = _state(col3)
+    assert ids == [f"a{i}" for i in range(10)] + [f"b{i}" for i in range(5)]
+    ref = emb[:15] / np.linalg.norm(emb[:15], axis=1, keepdims=True)
+    assert np.allclose(e, ref, atol=1e-6)           # b0..b4 carry THEIR vectors, not the orphan's
+    import json
+    recs = [json.loads(l) for l in open(os.path.join(d, col._cur_names()["jl"]))]
+    assert all("f32_off" in r and r["f32_len"] == r["n_emb"] * r["dim"] * 4 for r in recs if r["n_emb"])
+
+
+def test_journal_torn_last_line_is_dropped_and_the_next_record_starts_clean(tmp_path):
+    import os
+    cl = _open(tmp_path)
+    col = cl.create_collection("rag_dpo_chunks", metadata={"hnsw:space": "cosine"})
+    emb = synth.make_corpus(30, 64)
+    col.add(ids=["x0", "x1"], embeddings=emb[:2].tolist())
+    col.update(ids=["x0"], metadatas=[{"tags": "t"}])
+    jl = os.path.join(col._dir, col._cur_names()["jl"])
+    with open(jl, "ab") as f:
+        f.write(b'{"op": "add", "ids": ["torn0", "to')        # killed mid-line: no newline, invalid JSON
+    col2 = _open(tmp_path).get_collection("rag_dpo_chunks")
+    assert col2.get(include=[])["ids"] == ["x0", "x1"]
+    col2.add(ids=["y0"], embeddings=emb[2:3].tolist(), metadatas=[{"k": 1}])
+    col2.delete(ids=["x1"])
+    col3 = _open(tmp_path).get_collection("rag_dpo_chunks")      # the new records did not fuse with the torn one
+    assert col3.get(include=[])["ids"] == ["x0", "y0"]
+    assert col3.get(ids=["x0"])["metadatas"][0] == {"tags": "t"} and col3.get(ids=["y0"])["metadatas"][0] == {"k": 1}
+
+
+def test_persist_killed_before_or_after_its_commit_point(tmp_path):
+    """persist() writes generation g+1 beside g and commits by replacing collection.json: a kill before the commit leaves g
+    (+ its journal) in force, a kill right after leaves g+1 in force; the other generation's files go at the next open"""
+    import os
+    import shutil
+    cl = _open(tmp_path)
+    col = cl.create_collection("rag_dpo_chunks", metadata={"hnsw:space": "cosine"})
+    emb = synth.make_corpus(60, 64)
+    col.add(ids=[f"a{i}" for i in range(20)], embeddings=emb[:20].tolist(), documents=[f"d{i}" for i in range(20)])
+    cl.persist()                                                  # generation 1
+    col.add(ids=[f"b{i}" for i in range(5)], embeddings=emb[20:25].tolist())
+    col.delete(ids=["a3"])
+    want = _state(col)
+    d = col._dir
+    before = str(tmp_path / "before")
+    shutil.copytree(d, before)                                    # generation 1 + journal1
+    cl.persist()                                                  # generation 2
+    after_files = {fn: open(os.path.join(d, fn), "rb").read() for fn in os.listdir(d)}
+    # (a) killed BEFORE the commit: gen-2 snapshot files exist, the header still names gen 1
+    shutil.rmtree(d)
+    shutil.copytree(before, d)
+    for fn, blob in after_files.items():
+        if fn.startswith("snap2."):
+            open(os.path.join(d, fn), "wb").write(blob[: len(blob) // 2])    # half-written at that
+    got = _state(_open(tmp_path).get_collection("rag_dpo_chunks"))
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and (got[3] == want[3]).all()
+    assert not [fn for fn in os.listdir(d) if fn.startswith("snap2.")]
+    # (b) killed right AFTER the commit: header names gen 2, gen-1 files and journal1 are still lying around
+    shutil.rmtree(d)
+    shutil.copytree(before, d)
+    for fn, blob in after_files.items():
+        open(os.path.join(d, fn), "wb").write(blob)
+    got = _state(_open(tmp_path).get_collection("rag_dpo_chunks"))
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and (got[3] == want[3]).all()
+    assert sorted(os.listdir(d)) == sorted(after_files)           # journal1 was NOT replayed on top of snapshot 2, and is gone
+
+
+def test_reload_keeps_stored_vectors_bit_for_bit(tmp_path):
+    """snapshot rows are reloaded verbatim (engine.add_stored), not normalised a second time: distances before persist
+    and after reopen are the same floats (the reference indexes in one process and serves from another)"""
+    cl = _open(tmp_path)
+    col = cl.create_collection("rag_dpo_chunks", metadata={"hnsw:space": "cosine"})
+    emb, ids, docs, metas = fill(col, n=300)
+    q = synth.make_queries(3, 64, emb).tolist()
+    before = col.query(query_embeddings=q, n_results=40)
+    e0 = np.asarray(col.get(include=["embeddings"])["embeddings"])
+    for _ in range(3):                                             # three persist/open cycles
+        cl.persist()
+        cl = _open(tmp_path)
+        col = cl.get_collection("rag_dpo_chunks")
+    after = col.query(query_embeddings=q, n_results=40)
+    assert after["ids"] == before["ids"] and after["distances"] == before["distances"]
+    assert (np.asarray(col.get(include=["embeddings"])["embeddings"]) == e0).all()
+
+
+def test_bad_metadata_in_the_middle_of_a_batch_stores_nothing(tmp_path):
+    """every metadata value is validated before the engine sees the batch: host rows and device rows cannot diverge"""
+    col = Collection("c", engine_factory=oracle_factory)
+    emb = synth.make_corpus(12, 64)
+    col.add(ids=["a", "b"], embeddings=emb[:2].tolist(), metadatas=[{"n": 1}, {"n": 2}])
+    for bad in ({"n": 2 ** 60}, {5: "x"}, {"n": [1, 2]}, {"n": 10 ** 400}):
+        with pytest.raises((ValueError, OverflowError)):
+            col.add(ids=["c", "d", "e"], embeddings=emb[2:5].tolist(), metadatas=[{"n": 3}, bad, {"n": 5}])
+        assert col.count() == 2 and len(col._engine) == 2
+    with pytest.raises(ValueError):
+        col.update(ids=["a"], metadatas=[{"n": 2 ** 60}])
+    col.add(ids=["c", "d"], embeddings=emb[2:4].tolist(), metadatas=[{"n": 3}, {"n": 4}])
+    r = col.query(query_embeddings=emb[3:4].tolist(), n_results=1, where={"n": {"$gte": 3}})
+    assert r["ids"] == [["d"]] and r["metadatas"][0][0] == {"n": 4}

@@ -24,6 +24,9 @@ def test_persistent_client_gpu(tmp_path):
     col2 = PersistentClient(path=str(tmp_path / "db")).get_collection("rag_dpo_chunks")
     after = col2.query(query_embeddings=q, n_results=50, where={"source": "CNIL"})
     assert after["ids"] == before["ids"]
+    assert after["distances"] == before["distances"]      # stored rows reloaded verbatim (rdx_index_add_stored): same floats
+    import numpy as np
+    assert (np.asarray(col2.get(include=["embeddings"])["embeddings"]) == np.asarray(col.get(include=["embeddings"])["embeddings"])).all()
 
 
 def test_indexer_flow_gpu(tmp_path):

@@ -81,6 +81,28 @@ def test_baseline_config2(eng, oracle):
     ix.close()
 
 
+def test_xcd_shares_ignore_idle_workgroups(eng):
+    """nq = 600 -> three query tiles: 32 workgroups per XCD = 10 streams x 3 + 2 idle ones, which return before they stamp
+    their times. The XCD re-weighting must skip them (their stamp slots are stale memory): shares stay near an eighth and
+    the finish spread stays a sane number over repeated searches."""
+    rng = np.random.default_rng(3)
+    n, d = 270_000, 128
+    ix = eng.HipIndex(d)
+    for a in range(0, n, 90_000):
+        ix.add(rng.standard_normal((90_000, d)).astype(np.float32))
+    q = rng.standard_normal((600, d)).astype(np.float32)
+    for _ in range(5):
+        s, r, c = ix.search(q, 10)
+        st = ix.last_stats()
+        assert st["path"] == 0
+        assert 0.85 <= st["xcd_share_min"] <= 1.0 <= st["xcd_share_max"] <= 1.18, st
+        assert 0.0 <= st["xcd_finish_spread_ms"] < 1.0, st
+    ix.set_option("force_exact", 1)
+    xs, xr, xc = ix.search(q[:8], 10)
+    assert (xr == r[:8]).all() and (xs == s[:8]).all()
+    ix.close()
+
+
 def test_fast_path_other_dims(eng, oracle):
     rng = np.random.default_rng(11)
     for d in (768, 200, 64):
