@@ -111,6 +111,18 @@ int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out
 int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k, const uint32_t* allow_bits,
                float* out_score, int64_t* out_row, int32_t* out_count, int space, void* stream);
 
+/* Resident `where` bitmaps. The reference's filters are a handful of fixed shapes (src/rag/pipeline.py:35-71,
+ * pages/1_Chat.py:245-247) sent with every question: the host layer evaluates one ONCE, keeps the bitmap in HBM as an
+ * rdx_mask and passes the handle with every search instead of re-uploading count/8 bytes. allow_bits as in rdx_search
+ * (ceil(count/32) words, host or device). A mask belongs to the row count it was made for: any add / compact makes
+ * rdx_search_masked refuse it (RDX_ERR_STATE) — rebuild it (update of a row's vector does not change the count; the host
+ * layer drops its masks on every write anyway). mask == NULL = no filter. */
+typedef struct rdx_mask rdx_mask;
+int rdx_mask_create(rdx_index* h, const uint32_t* allow_bits, int space, rdx_mask** out);
+int rdx_mask_destroy(rdx_mask* m);
+int rdx_search_masked(rdx_index* h, const float* queries, int64_t nq, int k, const rdx_mask* mask, float* out_score,
+                      int64_t* out_row, int32_t* out_count, int space, void* stream);
+
 /* Multi-GPU exchange step: merge n_parts per-shard partial results (after the RCCL all-gather,
  * SURVEY.md §8e) into the global top-k with the same ordering rule. Layouts:
  * part_score/part_row [n_parts][nq][k], part_count [n_parts][nq]; row ids must already be global. */

@@ -65,6 +65,9 @@ SYMBOLS = {
     "rdx_index_set_option": (_i, [_vp, ctypes.c_char_p, _i64]),
     "rdx_l2_normalize": (_i, [_i, _vp, _i64, _i, _vp, _i, _vp]),
     "rdx_search": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "rdx_mask_create": (_i, [_vp, _vp, _i, ctypes.POINTER(_vp)]),
+    "rdx_mask_destroy": (_i, [_vp]),
+    "rdx_search_masked": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "rdx_merge_topk": (_i, [_i, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _vp]),
     "rdx_merge_topk_packed": (_i, [_i, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "rdx_search_last_stats": (_i, [_vp, ctypes.POINTER(SearchStats)]),

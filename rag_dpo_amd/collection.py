@@ -87,6 +87,11 @@ class Collection:
         self._lock = threading.RLock()
         self._client = _client
         self._meta_cache: Dict[int, Optional[dict]] = {}   # row -> metadata dict as last assembled (dropped on any write)
+        # `where` filters are a handful of fixed shapes re-sent with every question (reference src/rag/pipeline.py:35-71,
+        # pages/1_Chat.py:245-247): canonical JSON of the filter -> (packed bitmap, the engine's HBM-resident copy or None).
+        # Dropped on every write (add / update / delete / compaction): a bitmap describes one state of the rows.
+        self._mask_cache: "Dict[str, tuple]" = {}
+        self.mask_cache_hits = 0
         self._dir: Optional[str] = None        # set by PersistentClient: where the snapshot + journal live
         self._replaying = False
 
@@ -104,6 +109,8 @@ class Collection:
 
     def _set_meta(self, row: int, meta: Optional[dict], replace: bool):
         self._meta_cache.pop(row, None)
+        if self._mask_cache:
+            self._drop_masks()
         if replace:
             for col in self._cols.values():
                 col.kind[row] = W.K_MISSING
@@ -195,6 +202,42 @@ class Collection:
             m = self._alive[:n].copy() if m is None else (m & self._alive[:n])
         return m
 
+    _MASK_CACHE_MAX = 32
+
+    def _drop_masks(self):
+        for _, res in self._mask_cache.values():
+            if res is not None and hasattr(res, "close"):
+                res.close()
+        self._mask_cache.clear()
+
+    def _search_args(self, where: Optional[dict]) -> dict:
+        """-> keyword arguments for engine.search: nothing (no filter, no tombstones), mask= (resident bitmap of a filter
+        seen before or just uploaded) or allow_bits= (engines without resident masks)"""
+        if where in (None, {}) and not self._n_dead:
+            return {}
+        try:
+            key = json.dumps(where, sort_keys=True, ensure_ascii=False, allow_nan=False)
+        except (TypeError, ValueError):
+            key = None                                  # not canonicalisable: W.evaluate will say what is wrong with it
+        ent = self._mask_cache.get(key) if key is not None else None
+        if ent is None:
+            m = self._mask(where)
+            if m is None:
+                return {}
+            bits = W.pack_bits(m)
+            res = self._engine.make_mask(bits) if hasattr(self._engine, "make_mask") else None
+            ent = (bits, res)
+            if key is not None:
+                if len(self._mask_cache) >= self._MASK_CACHE_MAX:
+                    old = next(iter(self._mask_cache))          # oldest entry (insertion order)
+                    _, r0 = self._mask_cache.pop(old)
+                    if r0 is not None and hasattr(r0, "close"):
+                        r0.close()
+                self._mask_cache[key] = ent
+        else:
+            self.mask_cache_hits += 1
+        return {"mask": ent[1]} if ent[1] is not None else {"allow_bits": ent[0]}
+
     @staticmethod
     def _check_include(include: Sequence[str], allowed: set):
         for inc in include:
@@ -216,6 +259,7 @@ class Collection:
         self._row_of = {s: i for i, s in enumerate(self._ids)}
         self._n_dead = 0
         self._meta_cache.clear()
+        self._drop_masks()
 
     # ---- chromadb.Collection API ---------------------------------------------------------------
     def count(self) -> int:
@@ -256,6 +300,7 @@ class Collection:
             if metadatas is not None:   # validate EVERYTHING before anything is stored (host and device rows stay in step)
                 for i in fresh:
                     W.check_meta(metadatas[i])
+            self._drop_masks()
             sel = emb if len(fresh) == n else (emb[fresh].contiguous() if _is_device_tensor(emb) else np.ascontiguousarray(emb[fresh]))
             row0 = self._rows
             if _stored:             # snapshot reload: rows are the stored (already normalised) values, kept verbatim
@@ -343,6 +388,7 @@ class Collection:
                 raise ValueError("delete needs ids= or where=")
             gone = [self._ids[r] for r in rows if self._alive[r]]
             if gone:
+                self._drop_masks()
                 self._log({"op": "delete", "ids": gone}, None)
             for r in rows:
                 if self._alive[r]:
@@ -419,9 +465,7 @@ class Collection:
                         "uris": None, "data": None, "included": include}
             if q.shape[1] != self._dim:
                 raise ValueError(f"Embedding dimension {q.shape[1]} does not match collection dimensionality {self._dim}")
-            m = self._mask(where)
-            bits = W.pack_bits(m) if m is not None else None
-            scores, rows, counts = self._engine.search(q, int(n_results), bits)
+            scores, rows, counts = self._engine.search(q, int(n_results), **self._search_args(where))
             dist = (np.float32(1.0) - scores).astype(np.float32)   # Chroma cosine distance, fp32 like chromadb
             out_ids, out_docs, out_meta, out_dist, out_emb = [], [], [], [], []
             for b in range(nq):
@@ -661,6 +705,7 @@ class PersistentClient:
         if name not in self._cols:
             raise NotFoundError(f"Collection {name} does not exist.")
         c = self._cols.pop(name)
+        c._drop_masks()
         if c._engine is not None and hasattr(c._engine, "close"):
             c._engine.close()
         if self.path:

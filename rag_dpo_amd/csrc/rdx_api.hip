@@ -115,6 +115,13 @@ struct rdx_index {
     float two_e() const { return 2.0f * (1.0e-3f + 2.5e-7f * (float)dim_pad); }   // see DESIGN.md "error bound"
 };
 
+// a `where` bitmap kept resident in HBM between searches (the reference's filters are a handful of fixed shapes)
+struct rdx_mask {
+    int device = 0;
+    int64_t rows = 0;   // row count of the index when the mask was made: a mask never outlives a write to the index
+    DevBuf words;
+};
+
 static size_t shadow_bytes(const rdx_index* h, int64_t cap) { return (size_t)cap * h->dim_pad * 2; }
 
 static int set_device(const rdx_index* h) {
@@ -775,15 +782,15 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     return RDX_OK;
 }
 
-extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k, const uint32_t* allow_bits, float* out_score,
-                          int64_t* out_row, int32_t* out_count, int space, void* stream) {
+// allow_resident: allow_bits is already device memory whatever `space` says (a resident rdx_mask)
+static int search_impl(rdx_index* h, const float* queries, int64_t nq, int k, const uint32_t* allow_bits, bool allow_resident,
+                       float* out_score, int64_t* out_row, int32_t* out_count, int space, void* stream) {
     if (!h) return fail(RDX_ERR_INVALID, "rdx_search: null index");
     if (nq < 0 || k < 0) return fail(RDX_ERR_INVALID, "rdx_search: nq and k must be >= 0");
     if (k > SELECT_MAX_K) return fail(RDX_ERR_INVALID, "rdx_search: k larger than " + std::to_string(SELECT_MAX_K) + " is not supported");
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (nq == 0) return RDX_OK;
     if (!queries || !out_count || (k > 0 && (!out_score || !out_row))) return fail(RDX_ERR_INVALID, "rdx_search: null pointer");
-    std::lock_guard<std::mutex> lk(h->mu);
     RDX_TRY(set_device(h));
     // device pointers: the caller's stream as given (NULL = the default stream the caller produced its inputs on)
     hipStream_t st = (space == RDX_DEVICE || stream) ? (hipStream_t)stream : h->own_stream;
@@ -798,7 +805,7 @@ extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k,
 
     const uint32_t* d_allow = allow_bits;
     const size_t mask_words = (size_t)((h->rows + 31) / 32);
-    if (allow_bits && space == RDX_HOST && mask_words > 0) {
+    if (allow_bits && space == RDX_HOST && !allow_resident && mask_words > 0) {
         // pad to whole 256-row tiles so the scan may read the word of any block it touches
         const size_t pad_words = (size_t)((h->rows + 255) / 256 * 8);
         RDX_TRY(h->mask.ensure(pad_words * 4));
@@ -838,6 +845,61 @@ extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k,
     }
     h->stats = s;
     return RDX_OK;
+}
+
+extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k, const uint32_t* allow_bits, float* out_score,
+                          int64_t* out_row, int32_t* out_count, int space, void* stream) {
+    if (!h) return fail(RDX_ERR_INVALID, "rdx_search: null index");
+    std::lock_guard<std::mutex> lk(h->mu);
+    return search_impl(h, queries, nq, k, allow_bits, false, out_score, out_row, out_count, space, stream);
+}
+
+extern "C" int rdx_mask_create(rdx_index* h, const uint32_t* allow_bits, int space, rdx_mask** out) {
+    if (!h || !allow_bits || !out) return fail(RDX_ERR_INVALID, "rdx_mask_create: null pointer");
+    if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(set_device(h));
+    rdx_mask* m = new rdx_mask();
+    m->device = h->device;
+    m->rows = h->rows;
+    const size_t words = (size_t)((h->rows + 31) / 32), pad_words = (size_t)((h->rows + 255) / 256 * 8);
+    int rc = m->words.ensure(std::max<size_t>(pad_words, 8) * 4);
+    if (rc != RDX_OK) {
+        delete m;
+        return rc;
+    }
+    hipStream_t st = h->own_stream;
+    hipError_t e = hipMemsetAsync(m->words.p, 0, std::max<size_t>(pad_words, 8) * 4, st);
+    if (e == hipSuccess && words > 0) {
+        if (space == RDX_DEVICE) e = hipDeviceSynchronize();   // the caller's producer of the bits (any stream) is done
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(m->words.p, allow_bits, words * 4, space == RDX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        delete m;
+        return fail(RDX_ERR_HIP, std::string("rdx_mask_create: ") + hipGetErrorString(e));
+    }
+    *out = m;
+    return RDX_OK;
+}
+
+extern "C" int rdx_mask_destroy(rdx_mask* m) {
+    if (!m) return RDX_OK;
+    (void)hipSetDevice(m->device);
+    delete m;
+    return RDX_OK;
+}
+
+extern "C" int rdx_search_masked(rdx_index* h, const float* queries, int64_t nq, int k, const rdx_mask* mask, float* out_score,
+                                 int64_t* out_row, int32_t* out_count, int space, void* stream) {
+    if (!h) return fail(RDX_ERR_INVALID, "rdx_search_masked: null index");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (mask && (mask->device != h->device || mask->rows != h->rows))
+        return fail(RDX_ERR_STATE, "rdx_search_masked: the mask was made for " + std::to_string(mask->rows) + " rows on device " +
+                                       std::to_string(mask->device) + ", the index now holds " + std::to_string(h->rows) +
+                                       " (a mask does not outlive a write to the index)");
+    return search_impl(h, queries, nq, k, mask ? mask->words.as<uint32_t>() : nullptr, true, out_score, out_row, out_count, space, stream);
 }
 
 extern "C" int rdx_search_last_stats(rdx_index* h, rdx_search_stats* out) {

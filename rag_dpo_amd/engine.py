@@ -17,6 +17,24 @@ def _np_ptr(a: np.ndarray):
     return ctypes.c_void_p(a.ctypes.data)
 
 
+class ResidentMask:
+    """a `where` bitmap resident in HBM (rdx_mask): made once per distinct filter, passed with every search"""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            self._lib.rdx_mask_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipIndex:
     def __init__(self, dim: int, device: int = 0):
         self._lib = L.load(require_gpu=True)
@@ -100,9 +118,18 @@ class HipIndex:
         L.check(self._lib.rdx_index_compact(self._h, _np_ptr(keep), keep.shape[0]))
 
     # ---- search -----------------------------------------------------------------------------
-    def search(self, queries, k: int, allow_bits: Optional[np.ndarray] = None
+    def make_mask(self, allow_bits: np.ndarray) -> ResidentMask:
+        allow_bits = np.ascontiguousarray(allow_bits, dtype=np.uint32)
+        if allow_bits.shape[0] != (len(self) + 31) // 32:
+            raise ValueError("allow_bits must hold ceil(count/32) words")
+        h = ctypes.c_void_p()
+        L.check(self._lib.rdx_mask_create(self._h, _np_ptr(allow_bits), L.RDX_HOST, ctypes.byref(h)))
+        return ResidentMask(self._lib, h)
+
+    def search(self, queries, k: int, allow_bits: Optional[np.ndarray] = None, mask: Optional[ResidentMask] = None
                ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """Host in / host out. Returns (score f32[nq,k], row i64[nq,k], count i32[nq])."""
+        """Host in / host out. Returns (score f32[nq,k], row i64[nq,k], count i32[nq]).
+        allow_bits: host bitmap uploaded for this call; mask: a resident one (make_mask) — not both."""
         q = np.ascontiguousarray(queries, dtype=np.float32)
         if q.ndim != 2 or q.shape[1] != self.dim:
             raise ValueError(f"expected [nq][{self.dim}] query embeddings, got shape {q.shape}")
@@ -110,6 +137,12 @@ class HipIndex:
         sc = np.empty((nq, k), dtype=np.float32)
         ro = np.empty((nq, k), dtype=np.int64)
         cn = np.zeros((nq,), dtype=np.int32)
+        if mask is not None:
+            if allow_bits is not None:
+                raise ValueError("pass allow_bits or mask, not both")
+            L.check(self._lib.rdx_search_masked(self._h, _np_ptr(q), nq, int(k), mask._h, _np_ptr(sc), _np_ptr(ro), _np_ptr(cn),
+                                                L.RDX_HOST, None))
+            return sc, ro, cn
         mp = None
         if allow_bits is not None:
             allow_bits = np.ascontiguousarray(allow_bits, dtype=np.uint32)

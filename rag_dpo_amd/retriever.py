@@ -11,9 +11,13 @@ callable, sparse rankings can be passed in as extra rankings.
 """
 from __future__ import annotations
 
+import logging
 from collections import defaultdict
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Sequence
+
+
+logger = logging.getLogger(__name__)
 
 
 @dataclass
@@ -93,10 +97,27 @@ class DenseRetriever:
 
     # one batched device round trip for all the queries of a question
     def _dense(self, all_queries: List[str], n_fetch: int, where_filter):
+        """-> per sub-query its chunks, or None where `collection.query` raised for that sub-query: the reference calls
+        query once per sub-query inside a try and skips a failing one (src/rag/retriever.py:215-223, 380-388; an embed
+        failure is NOT caught there, :212, :377). Here the sub-queries go down as ONE batch; only when that batched call
+        raises (e.g. one NaN embedding rejects the batch) they are re-issued one at a time, so one bad sub-query costs
+        exactly that sub-query, as in the reference."""
         vectors = self.embedding_provider.embed(all_queries)       # reference: one embed([q]) per query (:212, :377)
-        results = self.collection.query(query_embeddings=vectors, n_results=n_fetch, where=where_filter,
-                                        include=["documents", "metadatas", "distances"])
-        return [parse_query_results(results, b) for b in range(len(all_queries))]
+        include = ["documents", "metadatas", "distances"]
+        try:
+            results = self.collection.query(query_embeddings=vectors, n_results=n_fetch, where=where_filter, include=include)
+            return [parse_query_results(results, b) for b in range(len(all_queries))]
+        except Exception as e:
+            logger.error("collection.query failed for the batch of %d sub-queries (%s): retrying one by one", len(all_queries), e)
+        out: List[Optional[List[RetrievedChunk]]] = []
+        for q_idx, v in enumerate(vectors):
+            try:
+                res = self.collection.query(query_embeddings=[v], n_results=n_fetch, where=where_filter, include=include)
+                out.append(parse_query_results(res, 0))
+            except Exception as e:
+                logger.error("collection.query failed (%s): %s", "principale" if q_idx == 0 else f"expansion #{q_idx}", e)
+                out.append(None)                                   # reference: `continue` (:221-223, :386-388)
+        return out
 
     def _queries(self, query: str) -> List[str]:
         expanded = self.query_preprocessor(query) if self.query_preprocessor else query
@@ -106,6 +127,8 @@ class DenseRetriever:
         all_rankings, weights = [], []
         chunk_map: Dict[str, RetrievedChunk] = {}
         for q_idx, chunks in enumerate(per_query):
+            if chunks is None:                                     # skipped sub-query: no ranking, no weight
+                continue
             for c in chunks:
                 c.semantic_score = c.similarity_score
             all_rankings.append([c.chunk_id for c in chunks])

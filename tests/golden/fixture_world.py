@@ -36,14 +36,18 @@ class HashEmbedder:
     """stands in for EmbeddingProvider: deterministic text -> vector near some corpus row"""
     model_name = "hash-embedder"
 
-    def __init__(self):
+    def __init__(self, poison_exact=(), poison_sub=()):
         self.c = corpus()
         self.calls = []
+        self.poison_exact, self.poison_sub = set(poison_exact), tuple(poison_sub)
 
     def embed(self, texts):
         self.calls.append(list(texts))
         out = []
         for t in texts:
+            if t in self.poison_exact or any(p in t for p in self.poison_sub):
+                out.append([float("nan")] * DIM)      # collection.query raises on it -> that sub-query is skipped
+                continue
             h = zlib.crc32(t.encode("utf-8"))
             v = self.c[h % N] + 0.8 * np.random.default_rng(h).standard_normal(DIM).astype(np.float32)
             out.append((v / np.linalg.norm(v)).astype(np.float32).tolist())
@@ -61,4 +65,14 @@ CASES = [
     {"query": "transfert hors union européenne",
      "where": {"$and": [{"chunk_nature": {"$in": ["GUIDE", "SANCTION"]}},
                         {"$or": [{"source": {"$ne": "ENTREPRISE"}}, {"tag_rh": True}]}]}, "n_candidates": 25},
+]
+
+# sub-queries whose collection.query raises (a NaN embedding): the reference logs and skips them
+# (src/rag/retriever.py:221-223, 386-388); always with the expander (4 sub-queries)
+FAIL_CASES = [
+    {"query": CASES[0]["query"], "where": None, "n_candidates": 40, "poison_exact": [], "poison_sub": ["obligations "]},
+    {"query": CASES[1]["query"], "where": CASES[1]["where"], "n_candidates": 60, "poison_exact": [CASES[1]["query"]], "poison_sub": []},
+    {"query": CASES[2]["query"], "where": CASES[2]["where"], "n_candidates": 25, "poison_exact": [],
+     "poison_sub": ["(reformulation", "obligations ", " sanction"]},
+    {"query": CASES[0]["query"], "where": None, "n_candidates": 40, "poison_exact": [], "poison_sub": ["onn"]},   # every sub-query fails
 ]

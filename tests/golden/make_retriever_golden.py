@@ -85,6 +85,18 @@ def main():
                                             "primary_nature": d.primary_nature, "chunks": [chunk_dict(c) for c in d.chunks]}
                                            for d in docs]},
             })
+    out["fail_cases"] = []
+    for case in W.FAIL_CASES:
+        rec = Recorder(W.build_collection(factory))
+        emb = W.HashEmbedder(case["poison_exact"], case["poison_sub"])
+        r = RAGRetriever(collection=rec, llm_provider=None, embedding_provider=emb, summary_bm25_index=None,
+                         chunk_bm25_index=None, query_expander=Expander())
+        cands = r.retrieve_candidates(case["query"], n_candidates=case["n_candidates"], where_filter=case["where"])
+        n_calls = len(rec.seen)
+        docs = r.retrieve(case["query"], where_filter=case["where"])
+        out["fail_cases"].append({**case, "collection_query_calls": n_calls, "chunks": [chunk_dict(c) for c in cands],
+                                  "documents": [{"document_path": d.document_path, "avg_similarity": d.avg_similarity,
+                                                 "chunks": [chunk_dict(c) for c in d.chunks]} for d in docs]})
     with open(os.path.join(HERE, "retriever_golden.json"), "w", encoding="utf-8") as f:
         json.dump(out, f, ensure_ascii=False, indent=1)
     print("wrote", len(out["cases"]), "cases")

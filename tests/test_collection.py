@@ -323,3 +323,77 @@ def test_bad_metadata_in_the_middle_of_a_batch_stores_nothing(tmp_path):
     col.add(ids=["c", "d"], embeddings=emb[2:4].tolist(), metadatas=[{"n": 3}, {"n": 4}])
     r = col.query(query_embeddings=emb[3:4].tolist(), n_results=1, where={"n": {"$gte": 3}})
     assert r["ids"] == [["d"]] and r["metadatas"][0][0] == {"n": 4}
+
+
+def run_mask_cache(factory):
+    """a filter seen before is not evaluated or uploaded again; any write drops the cached bitmaps; results never change"""
+    col = Collection("c", engine_factory=factory)
+    emb, ids, docs, metas = fill(col, n=400)
+    q = synth.make_queries(2, 64, emb).tolist()
+    w1 = {"$and": [{"chunk_nature": {"$in": ["GUIDE", "DOCTRINE"]}}, {"$or": [{"source": {"$ne": "ENTREPRISE"}}, {"tag_rh": True}]}]}
+    w1_reordered = {"$and": [{"chunk_nature": {"$in": ["GUIDE", "DOCTRINE"]}}, {"$or": [{"source": {"$ne": "ENTREPRISE"}}, {"tag_rh": True}]}]}
+    a = col.query(query_embeddings=q, n_results=30, where=w1)
+    assert col.mask_cache_hits == 0 and len(col._mask_cache) == 1
+    b = col.query(query_embeddings=q, n_results=30, where=w1_reordered)
+    assert col.mask_cache_hits == 1 and a == b
+    col.query(query_embeddings=q, n_results=30, where={"source": "CNIL"})
+    assert len(col._mask_cache) == 2
+    assert col.query(query_embeddings=q, n_results=30) == col.query(query_embeddings=q, n_results=30, where={})   # no filter: no mask
+    assert len(col._mask_cache) == 2
+    # writes invalidate: metadata update changes who passes
+    first = a["ids"][0][0]
+    col.update(ids=[first], metadatas=[{"chunk_nature": "SANCTION"}])
+    assert not col._mask_cache
+    c = col.query(query_embeddings=q, n_results=30, where=w1)
+    assert first not in c["ids"][0] and c["ids"][0][:5] == a["ids"][0][1:6]
+    # add: the new row passes the cached filter's successor, never a stale bitmap of the old row count
+    col.add(ids=["new"], embeddings=[q[0]], metadatas=[{"chunk_nature": "GUIDE", "source": "CNIL"}])
+    assert not col._mask_cache
+    d = col.query(query_embeddings=q, n_results=5, where=w1)
+    assert d["ids"][0][0] == "new"
+    # delete: tombstones are part of every bitmap, also of the "no filter" one
+    col.delete(ids=["new"])
+    e = col.query(query_embeddings=q, n_results=5, where=w1)
+    assert e["ids"][0] == c["ids"][0][:5]
+    f1 = col.query(query_embeddings=q, n_results=5)
+    f2 = col.query(query_embeddings=q, n_results=5)
+    assert "new" not in f1["ids"][0] and f1 == f2 and col.mask_cache_hits >= 2
+    # bounded
+    for i in range(Collection._MASK_CACHE_MAX + 5):
+        col.query(query_embeddings=q, n_results=1, where={"chunk_index": {"$gte": i}})
+    assert len(col._mask_cache) <= Collection._MASK_CACHE_MAX
+    return col
+
+
+def test_mask_cache_cpu():
+    run_mask_cache(oracle_factory)
+
+
+def test_mask_cache_uses_resident_masks_when_the_engine_has_them():
+    from oracle_engine import OracleEngine
+
+    class ResidentEngine(OracleEngine):
+        made, closed, used = 0, 0, 0
+
+        def make_mask(self, bits):
+            ResidentEngine.made += 1
+            outer = self
+
+            class M:
+                def __init__(s):
+                    s.bits, s.rows = np.array(bits), len(outer)
+
+                def close(s):
+                    ResidentEngine.closed += 1
+            return M()
+
+        def search(self, q, k, allow_bits=None, mask=None):
+            if mask is not None:
+                assert mask.rows == len(self)        # a mask never outlives a write
+                ResidentEngine.used += 1
+                allow_bits = mask.bits
+            return super().search(q, k, allow_bits)
+
+    run_mask_cache(lambda dim, device=0: ResidentEngine(dim, device))
+    assert ResidentEngine.made > 5 and ResidentEngine.used > ResidentEngine.made
+    assert ResidentEngine.closed >= ResidentEngine.made - Collection._MASK_CACHE_MAX

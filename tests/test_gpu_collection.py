@@ -67,3 +67,23 @@ def test_indexer_device_embeddings_route(tmp_path):
     c = again.get(include=["embeddings"])
     assert c["ids"] == b["ids"]
     np.testing.assert_allclose(np.asarray(c["embeddings"]), np.asarray(b["embeddings"]), rtol=0, atol=2.5e-7)
+
+
+def test_mask_cache_gpu():
+    """the same filter/invalidations contract with HBM-resident rdx_mask objects; a stale mask is refused by the library"""
+    import numpy as np
+    from test_collection import run_mask_cache
+    from rag_dpo_amd.engine import ResidentMask
+    col = run_mask_cache(None)
+    assert all(isinstance(r, ResidentMask) for _, r in col._mask_cache.values())
+    eng = col._engine
+    n = len(eng)
+    m = eng.make_mask(np.full((n + 31) // 32, 0xFFFFFFFF, dtype=np.uint32))
+    q = np.ones((1, eng.dim), dtype=np.float32)
+    a = eng.search(q, 3, mask=m)
+    b = eng.search(q, 3)
+    assert (a[1] == b[1]).all() and (a[0] == b[0]).all()
+    eng.add(np.ones((1, eng.dim), dtype=np.float32))
+    import pytest
+    with pytest.raises(Exception, match="mask"):
+        eng.search(q, 3, mask=m)

@@ -67,6 +67,43 @@ def replay(engine_factory):
                 _same_chunk(c, gc)
 
 
+def replay_failures(engine_factory):
+    """sub-queries whose collection.query raises are skipped the way the reference skips them: same chunks, scores and
+    documents as the reference retriever produced with the same poisoned embedder (one call per sub-query there; here one
+    batched call that fails, then one call per sub-query)"""
+    for case in GOLD["fail_cases"]:
+        col = W.build_collection(engine_factory)
+        calls = []
+        real_query = col.query
+
+        def spy(**kw):
+            calls.append(len(kw["query_embeddings"]))
+            return real_query(**kw)
+        col.query = spy
+        r = DenseRetriever(col, W.HashEmbedder(case["poison_exact"], case["poison_sub"]), query_expander=W.expander)
+        cands = r.retrieve_candidates(case["query"], n_candidates=case["n_candidates"], where_filter=case["where"])
+        assert calls == [4, 1, 1, 1, 1]
+        assert len(cands) == len(case["chunks"])
+        for c, g in zip(cands, case["chunks"]):
+            _same_chunk(c, g)
+        docs = r.retrieve(case["query"], where_filter=case["where"])
+        assert [d.document_path for d in docs] == [g["document_path"] for g in case["documents"]]
+        for d, g in zip(docs, case["documents"]):
+            assert d.avg_similarity == g["avg_similarity"]
+            for c, gc in zip(d.chunks, g["chunks"]):
+                _same_chunk(c, gc)
+
+
+def test_replay_failures_cpu():
+    from oracle_engine import factory
+    replay_failures(factory)
+
+
+@pytest.mark.gpu
+def test_replay_failures_gpu():
+    replay_failures(None)
+
+
 def test_replay_cpu():
     from oracle_engine import factory
     replay(factory)
