@@ -84,6 +84,13 @@ int rdx_index_get(rdx_index* h, const int64_t* row_ids, int64_t n, float* out, i
  * listed in `keep` (strictly ascending, host pointer), renumbering them 0..n_keep-1. */
 int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep);
 
+/* Shards whose rows are not one contiguous range of the collection (several GPUs behind ONE `collection` object, rows
+ * dealt to the devices as they arrive): returned row id of local row r = ids[r]. ids must be strictly increasing over the
+ * shard (ties inside a shard are ordered by local row, which then is the order of the returned ids too). Sets the ids
+ * of rows [first_row, first_row + n), which must exist; rows never given an id return local + "row_base". An index
+ * without a map (the default) returns local + "row_base". rdx_index_compact drops the map (rows are renumbered). */
+int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, int64_t n, int space);
+
 /* Options (tests and benchmarks): "force_exact" 0/1, "force_fast" 0/1 (MFMA scan even for small
  * problems), "sample_div" >=1, "cand_cap" 0 (auto) or slots per (query, stream) candidate segment,
  * "profile" 0/1 (record HIP events around every kernel of the next searches); "row_base" >= 0:

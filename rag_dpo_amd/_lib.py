@@ -62,6 +62,7 @@ SYMBOLS = {
     "rdx_index_update": (_i, [_vp, _vp, _vp, _i64, _i]),
     "rdx_index_get": (_i, [_vp, _vp, _i64, _vp, _i]),
     "rdx_index_compact": (_i, [_vp, _vp, _i64]),
+    "rdx_index_set_row_ids": (_i, [_vp, _i64, _vp, _i64, _i]),
     "rdx_index_set_option": (_i, [_vp, ctypes.c_char_p, _i64]),
     "rdx_l2_normalize": (_i, [_i, _vp, _i64, _i, _vp, _i, _vp]),
     "rdx_search": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),

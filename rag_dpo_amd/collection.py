@@ -43,6 +43,17 @@ def _default_engine_factory(dim: int, device: int):
     return HipIndex(dim, device)
 
 
+def _devices_from_env() -> Optional[List[int]]:
+    """RDX_DEVICES=all | "0,1,2,3": spread every collection of this process over these GPUs (rag_dpo_amd.multi_device)"""
+    v = os.environ.get("RDX_DEVICES", "").strip()
+    if not v:
+        return None
+    if v.lower() == "all":
+        from .multi_device import visible_devices
+        return visible_devices()
+    return [int(x) for x in v.split(",") if x.strip() != ""]
+
+
 def _is_device_tensor(x) -> bool:
     import sys
     torch = sys.modules.get("torch")
@@ -68,13 +79,24 @@ def _as_matrix(embeddings, what: str):
 
 class Collection:
     def __init__(self, name: str, metadata: Optional[dict] = None, device: int = 0,
-                 engine_factory: Optional[Callable[[int, int], Any]] = None, _client=None):
+                 engine_factory: Optional[Callable[[int, int], Any]] = None, _client=None,
+                 devices: Optional[Sequence[int]] = None):
+        """devices=[0, 1, ...] (or RDX_DEVICES in the environment): the rows of this ONE collection object are sharded over
+        these GPUs and every query spans them (rag_dpo_amd.multi_device) — the reference's single shared `collection`
+        (app.py:42-67) on up to 8 MI355X. Default: one GPU (`device`)."""
         self.name = name
         self.metadata = dict(metadata or {})
         space = self.metadata.get("hnsw:space", "cosine")
         if space != "cosine":
             raise ValueError(f"only the cosine space is implemented (the reference uses 'hnsw:space': 'cosine'), got {space!r}")
         self._device = device
+        if engine_factory is None:
+            devs = list(devices) if devices is not None else _devices_from_env()
+            if devs is not None and len(devs) > 1:
+                from .multi_device import multi_device_factory
+                engine_factory = multi_device_factory(devs)
+            elif devs:
+                self._device = device = int(devs[0])
         self._factory = engine_factory or _default_engine_factory
         self._engine = None
         self._dim: Optional[int] = None
@@ -667,9 +689,13 @@ class PersistentClient:
     Collections are loaded into HBM on open; every add/update/delete is journalled when it returns, persist()/close()
     fold the journal into a snapshot."""
 
-    def __init__(self, path: Optional[str] = None, device: int = 0, engine_factory=None, settings=None, **_ignored):
+    def __init__(self, path: Optional[str] = None, device: int = 0, engine_factory=None, settings=None,
+                 devices: Optional[Sequence[int]] = None, **_ignored):
         self.path = path
         self._device = device
+        if engine_factory is None and devices is not None and len(devices) > 1:
+            from .multi_device import multi_device_factory
+            engine_factory = multi_device_factory(devices)
         self._factory = engine_factory
         self._cols: Dict[str, Collection] = {}
         if path and os.path.isdir(path):

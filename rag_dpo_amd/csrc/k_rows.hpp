@@ -80,6 +80,12 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
     }
 }
 
+// row_map[first + i] = base + first + i (identity part of a shard's local -> global row id map)
+__global__ __launch_bounds__(256) void k_iota64(int64_t* __restrict__ out, int64_t first, int64_t n, int64_t base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[first + i] = base + first + i;
+}
+
 // rebuild the scan copy of rows [row0, row0+n) from the (already normalised) master copy
 __global__ __launch_bounds__(256) void k_reshadow(const float* __restrict__ master, int64_t row0, int64_t n, int dim,
                                                   _Float16* __restrict__ shadow, int ksteps, float scale) {
@@ -198,6 +204,7 @@ __device__ __forceinline__ void rank_and_write(const float* __restrict__ s, cons
 constexpr int SELECT_MAX_K = 4096;
 __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__ scores, int64_t rows,
                                                        const int32_t* __restrict__ q_list, int k, int64_t row_base,
+                                                       const int64_t* __restrict__ row_map,
                                                        float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                        int32_t* __restrict__ out_count) {
     __shared__ uint32_t hist[256];
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
         if (key > kth) {
             const int pos = atomicAdd(&n_sel, 1);
             s_s[pos] = v;
-            s_r[pos] = row_base + i;
+            s_r[pos] = row_map ? row_map[i] : row_base + i;
         } else if (key == kth) {
             const int e = atomicAdd(&n_eq, 1);
             if (e < EQ_CAP) eq_idx[e] = i;
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
             for (int f = 0; f < ne; ++f) rank += eq_idx[f] < i;
             if (rank < need_eq) {
                 s_s[(int)n_gt + rank] = sc[i];
-                s_r[(int)n_gt + rank] = row_base + i;
+                s_r[(int)n_gt + rank] = row_map ? row_map[i] : row_base + i;
             }
         }
     } else {
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
             const int my = before + __popcll(m & ((1ull << lane) - 1ull));
             if (eq && my < need_eq) {
                 s_s[(int)n_gt + my] = sc[i];
-                s_r[(int)n_gt + my] = row_base + i;
+                s_r[(int)n_gt + my] = row_map ? row_map[i] : row_base + i;
             }
             __syncthreads();
             if (threadIdx.x == 0) {

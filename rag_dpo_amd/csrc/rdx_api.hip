@@ -100,6 +100,7 @@ struct rdx_index {
     int sample_div = 64;
     int64_t cand_cap = 0;   // 0 = automatic
     int64_t row_base = 0;   // added to every returned row id (global ids of a shard)
+    int64_t* row_map = nullptr;   // [cap] local row -> returned row id (strictly increasing), or NULL = local + row_base
 
     // scratch (grow-only; never allocated inside a warmed-up search)
     DevBuf r_list, r_q, r_s, r_r, r_c;   // second-chance batch of overflowed queries
@@ -149,6 +150,17 @@ static int grow(rdx_index* h, int64_t need_rows) {
         return fail(RDX_ERR_NOMEM, std::string("growing index to ") + std::to_string(ncap) + " rows: " + hipGetErrorString(e));
     }
     hipStream_t st = h->own_stream;
+    int64_t* nr = nullptr;
+    if (h->row_map) {   // the id map grows with the rows: old entries kept, new ones start as local + row_base
+        e = hipMalloc((void**)&nr, (size_t)ncap * 8);
+        if (e != hipSuccess) {
+            (void)hipFree(nm);
+            (void)hipFree(ns);
+            return fail(RDX_ERR_NOMEM, std::string("growing the row id map: ") + hipGetErrorString(e));
+        }
+        if (h->rows > 0) HIP_TRY(hipMemcpyAsync(nr, h->row_map, (size_t)h->rows * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_iota64, dim3((unsigned)((ncap - h->rows + 255) / 256)), dim3(256), 0, st, nr, h->rows, ncap - h->rows, h->row_base);
+    }
     HIP_TRY(hipMemsetAsync(ns, 0, shadow_bytes(h, ncap), st));
     if (h->rows > 0) {
         HIP_TRY(hipMemcpyAsync(nm, h->master, (size_t)h->rows * h->dim * 4, hipMemcpyDeviceToDevice, st));
@@ -157,8 +169,10 @@ static int grow(rdx_index* h, int64_t need_rows) {
     HIP_TRY(hipStreamSynchronize(st));
     if (h->master) (void)hipFree(h->master);
     if (h->shadow) (void)hipFree(h->shadow);
+    if (h->row_map) (void)hipFree(h->row_map);
     h->master = nm;
     h->shadow = ns;
+    h->row_map = nr;
     h->cap = ncap;
     return RDX_OK;
 }
@@ -216,6 +230,7 @@ extern "C" int rdx_index_destroy(rdx_index* h) {
     (void)hipStreamSynchronize(h->own_stream);
     if (h->master) (void)hipFree(h->master);
     if (h->shadow) (void)hipFree(h->shadow);
+    if (h->row_map) (void)hipFree(h->row_map);
     for (DevBuf* b : {&h->staging, &h->qraw, &h->qhat, &h->qshadow, &h->tau, &h->cntw, &h->cand, &h->setmax, &h->exact_list,
                       &h->iota, &h->dense, &h->ctr, &h->bad, &h->o_score, &h->o_row, &h->o_count, &h->mask, &h->ids,
                       &h->sib_scratch, &h->r_list, &h->r_q, &h->r_s, &h->r_r, &h->r_c})
@@ -424,10 +439,37 @@ extern "C" int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_ke
     HIP_TRY(hipStreamSynchronize(st));
     if (h->master) (void)hipFree(h->master);
     if (h->shadow) (void)hipFree(h->shadow);
+    if (h->row_map) (void)hipFree(h->row_map);   // rows were renumbered: the caller sets a new id map (or none)
+    h->row_map = nullptr;
     h->master = nm;
     h->shadow = ns;
     h->cap = ncap;
     h->rows = n_keep;
+    return RDX_OK;
+}
+
+extern "C" int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, int64_t n, int space) {
+    if (!h || first_row < 0 || n < 0 || (n > 0 && !ids)) return fail(RDX_ERR_INVALID, "rdx_index_set_row_ids: bad argument");
+    if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (first_row + n > h->rows) return fail(RDX_ERR_INVALID, "rdx_index_set_row_ids: rows [first_row, first_row + n) must exist");
+    if (n == 0) return RDX_OK;
+    RDX_TRY(set_device(h));
+    hipStream_t st = h->own_stream;
+    if (space == RDX_HOST) {
+        for (int64_t i = 0; i < n; ++i)
+            if (ids[i] < 0 || (i > 0 && ids[i] <= ids[i - 1]))
+                return fail(RDX_ERR_INVALID, "rdx_index_set_row_ids: ids must be non-negative and strictly increasing");
+    } else {
+        HIP_TRY(hipDeviceSynchronize());   // the caller's producer of `ids` (any stream) is done
+    }
+    if (!h->row_map) {
+        HIP_TRY(hipMalloc((void**)&h->row_map, (size_t)std::max<int64_t>(h->cap, 256) * 8));
+        hipLaunchKernelGGL(k_iota64, dim3((unsigned)((h->cap + 255) / 256)), dim3(256), 0, st, h->row_map, (int64_t)0, h->cap, h->row_base);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(h->row_map + first_row, ids, (size_t)n * 8, space == RDX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return RDX_OK;
 }
 
@@ -521,7 +563,7 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_select_dense, dim3(nq), dim3(1024), 0, st, h->dense.as<float>(), h->rows, d_list + j0, k, h->row_base,
-                           d_score, d_row, d_count);
+                           h->row_map, d_score, d_row, d_count);
         HIP_TRY(hipGetLastError());
     }
     return RDX_OK;
@@ -692,7 +734,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             const size_t lds = (size_t)list_cap * 8;
             RDX_TRY(ensure_dynamic_lds(h, (const void*)k_refine, lds));
             hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(k > 32 ? 1024 : 256), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
-                               list_cap, k, h->two_e(), h->qhat.as<float>(), h->master, h->dim, h->row_base, d_score, d_row, d_count,
+                               list_cap, k, h->two_e(), h->qhat.as<float>(), h->master, h->dim, h->row_base, h->row_map, d_score, d_row, d_count,
                                h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
             HIP_TRY(hipGetLastError());
         }

@@ -26,7 +26,8 @@ struct RefineCounters {   // one per index, zeroed before every search
 __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
                                                 int n_streams, uint32_t capw, uint32_t list_cap, int k, float two_e,
                                                 const float* __restrict__ qhat, const float* __restrict__ master, int dim,
-                                                int64_t row_base, float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                                int64_t row_base, const int64_t* __restrict__ row_map,
+                                                float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                 int32_t* __restrict__ out_count, int32_t* __restrict__ exact_list,
                                                 RefineCounters* __restrict__ ctr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand,
         if (lane == 0) s_s[i] = s;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < p; i += blockDim.x) s_r[i] += row_base;
+    // local -> returned row id: + row_base, or through the shard's (strictly increasing) row id map
+    for (int i = threadIdx.x; i < p; i += blockDim.x) s_r[i] = row_map ? row_map[s_r[i]] : s_r[i] + row_base;
     __syncthreads();
     rank_and_write(s_s, s_r, p, k, o_s, o_r, out_count + q);
 }

@@ -113,6 +113,11 @@ class HipIndex:
         L.check(self._lib.rdx_index_get(self._h, _np_ptr(ids), ids.shape[0], _np_ptr(out), L.RDX_HOST))
         return out
 
+    def set_row_ids(self, first_row: int, ids):
+        """returned row id of local row first_row + i = ids[i] (strictly increasing over the shard)"""
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        L.check(self._lib.rdx_index_set_row_ids(self._h, int(first_row), _np_ptr(a), a.shape[0], L.RDX_HOST))
+
     def compact(self, keep_rows):
         keep = np.ascontiguousarray(keep_rows, dtype=np.int64)
         L.check(self._lib.rdx_index_compact(self._h, _np_ptr(keep), keep.shape[0]))
