@@ -190,6 +190,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
     ap.add_argument("--no-encode", action="store_true", help="c5: leave the BGE-M3 query encode out of the step")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="developer: rdx_index_set_option before the run")
+    ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel of a search (path_stats.ms), not only the main scan")
     ap.add_argument("--check-merged", action="store_true",
                     help="N>1: rank 0 also builds the WHOLE corpus in one index and checks that the merged result is bit-identical")
     args = ap.parse_args()
@@ -234,7 +235,9 @@ def main():
     log(f"[rank {rank}] shard rows [{lo}, {hi}) resident in {time.time() - t_build:.1f}s")
     searcher = ShardedSearcher(shard, host_staged=rehearsal)
     queries, planted = synth.torch_queries(B, dim, device, total_rows=rows, return_planted=True)   # 10 % planted (§8d)
-    shard.index.set_option("profile", 1)    # HIP events around every kernel, on the stream they run on
+    # HIP events on the stream the kernels run on: 2 = around the dominant kernel (the main scan) only, which is what the
+    # timed region carries; --profile-all records every kernel boundary (7 events per search: visible in small configs)
+    shard.index.set_option("profile", 1 if args.profile_all else 2)
     for kv in args.set:
         shard.index.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
@@ -13,6 +14,8 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include <immintrin.h>
 
 #include "k_rows.hpp"
 #include "refine_kernel.hpp"
@@ -108,6 +111,14 @@ struct rdx_index {
     std::unordered_map<const void*, size_t> func_lds;   // dynamic-LDS limit already raised for a kernel ON THIS DEVICE
     DevBuf sib_scratch, staging, qraw, qhat, qshadow, tau, cntw, cand, setmax, exact_list, iota, dense, ctr, bad, o_score, o_row,
         o_count, mask, ids;
+    // end-of-search mailbox in pinned host memory (k_finish writes it over PCIe; the host spins on its sequence number)
+    Mailbox* mbox = nullptr;          // host address
+    Mailbox* mbox_dev = nullptr;      // the same memory as the device sees it
+    unsigned long long seq = 0;       // number of the last search enqueued on this index
+    char* pin_out = nullptr;          // pinned staging for the small results of host callers (score | row | count)
+    char* pin_out_dev = nullptr;
+    size_t pin_out_bytes = 0;
+    bool ctr_ready = false;           // the counter block was zeroed once; afterwards every k_finish re-zeroes it
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
     rdx_search_stats stats = {};
@@ -235,6 +246,8 @@ extern "C" int rdx_index_destroy(rdx_index* h) {
                       &h->iota, &h->dense, &h->ctr, &h->bad, &h->o_score, &h->o_row, &h->o_count, &h->mask, &h->ids,
                       &h->sib_scratch, &h->r_list, &h->r_q, &h->r_s, &h->r_r, &h->r_c})
         b->release();
+    if (h->mbox) (void)hipHostFree(h->mbox);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->ev_ok)
         for (auto& e : h->ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(h->own_stream);
@@ -274,7 +287,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
         for (double& w : h->xw) w = 1.0;
     }
     else if (n == "sib_lag") h->sib_lag = (int)std::min<int64_t>(std::max<int64_t>(value, 3), 100);
-    else if (n == "profile") h->profile = value != 0;
+    else if (n == "profile") h->profile = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
     else if (n == "sample_div") {
         if (value < 1) return fail(RDX_ERR_INVALID, "sample_div must be >= 1");
         h->sample_div = (int)std::min<int64_t>(value, 1 << 20);
@@ -473,45 +486,43 @@ extern "C" int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int6
     return RDX_OK;
 }
 
+// scratch of rdx_l2_normalize, kept per device (the call sits on the embed() path of every query: no hipMalloc/hipFree per call)
+struct NormScratch {
+    std::mutex mu;
+    DevBuf in, out, bad;
+};
+static NormScratch g_norm[64];
+
 extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space, void* stream) {
     if (n < 0 || (n > 0 && (!in || !out))) return fail(RDX_ERR_INVALID, "rdx_l2_normalize: bad argument");
     RDX_TRY(check_dim(dim));
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_l2_normalize: device out of range");
     if (n == 0) return RDX_OK;
     HIP_TRY(hipSetDevice(device));
+    NormScratch& sc = g_norm[device];
+    std::lock_guard<std::mutex> lk(sc.mu);
     hipStream_t st = (hipStream_t)stream;
     const float* d_in = in;
     float* d_out = out;
-    DevBuf bi, bo, bad;
-    RDX_TRY(bad.ensure(sizeof(int)));
+    RDX_TRY(sc.bad.ensure(sizeof(int)));
     if (space == RDX_HOST) {
-        RDX_TRY(bi.ensure((size_t)n * dim * 4));
-        RDX_TRY(bo.ensure((size_t)n * dim * 4));
-        HIP_TRY(hipMemcpyAsync(bi.p, in, (size_t)n * dim * 4, hipMemcpyHostToDevice, st));
-        d_in = bi.as<float>();
-        d_out = bo.as<float>();
+        RDX_TRY(sc.in.ensure((size_t)n * dim * 4));
+        RDX_TRY(sc.out.ensure((size_t)n * dim * 4));
+        HIP_TRY(hipMemcpyAsync(sc.in.p, in, (size_t)n * dim * 4, hipMemcpyHostToDevice, st));
+        d_in = sc.in.as<float>();
+        d_out = sc.out.as<float>();
     }
-    HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(sc.bad.p, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_normalize<false>, dim3((int)((n + 3) / 4)), dim3(256), 0, st, d_in, (const uint16_t*)nullptr, n, dim,
-                       (const int64_t*)nullptr, (int64_t)0, d_out, (_Float16*)nullptr, 0, 1.0f, bad.as<int>());
+                       (const int64_t*)nullptr, (int64_t)0, d_out, (_Float16*)nullptr, 0, 1.0f, sc.bad.as<int>());
     HIP_TRY(hipGetLastError());
-    int rc = RDX_OK;
-    if (space == RDX_HOST) {
-        int b = 0;
-        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * dim * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&b, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (b) rc = fail(RDX_ERR_INVALID, "embeddings contain NaN or Inf");
-    } else {
-        int b = 0;
-        HIP_TRY(hipMemcpyAsync(&b, bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));   // scratch below is freed on return
-        if (b) rc = fail(RDX_ERR_INVALID, "embeddings contain NaN or Inf");
-    }
-    bi.release();
-    bo.release();
-    bad.release();
-    return rc;
+    int b = 0;
+    if (space == RDX_HOST) HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * dim * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&b, sc.bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the NaN/Inf verdict is part of the return value
+    if (b) return fail(RDX_ERR_INVALID, "embeddings contain NaN or Inf");
+    return RDX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -569,9 +580,9 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
     return RDX_OK;
 }
 
-// Host callers: where the results go. They are copied back in front of the search's ONE host synchronisation (the
-// counter read-back); only when that read-back shows that a fallback pass had to rewrite some results are they copied
-// again (HostOut::stale).
+// Host callers: where the results go. Small results travel with the end-of-search kernel into pinned staging and are
+// copied to the caller's buffers by the CPU once the mailbox says the search is complete; large ones use D2H copies.
+// When a fallback pass had to rewrite some results afterwards they are copied again (HostOut::stale).
 struct HostOut {
     float* score;
     int64_t* row;
@@ -579,23 +590,67 @@ struct HostOut {
     bool stale;
 };
 
+static const size_t PIN_MAX = 256 * 1024;   // results up to this size ride with k_finish (one block writing over PCIe)
+
+static int ensure_mailbox(rdx_index* h) {
+    if (h->mbox) return RDX_OK;
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, sizeof(Mailbox), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(p, 0, sizeof(Mailbox));
+    void* d = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&d, p, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(p);
+        return fail(RDX_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    }
+    h->mbox = reinterpret_cast<Mailbox*>(p);
+    h->mbox_dev = reinterpret_cast<Mailbox*>(d);
+    return RDX_OK;
+}
+
+static int ensure_pin_out(rdx_index* h, size_t bytes) {
+    if (bytes <= h->pin_out_bytes) return RDX_OK;
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    h->pin_out = nullptr;
+    h->pin_out_bytes = 0;
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, PIN_MAX, hipHostMallocMapped | hipHostMallocCoherent));
+    void* d = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&d, p, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(p);
+        return fail(RDX_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    }
+    h->pin_out = reinterpret_cast<char*>(p);
+    h->pin_out_dev = reinterpret_cast<char*>(d);
+    h->pin_out_bytes = PIN_MAX;
+    return RDX_OK;
+}
+
+// The search numbered `seq` has completed: its k_finish published the mailbox. Spin on the pinned word for a while
+// (short searches: the store arrives a couple of us after the kernel, no interrupt, no D2H copy), then fall back to
+// hipStreamSynchronize (long searches; it also surfaces a faulted kernel).
+static int wait_search(rdx_index* h, hipStream_t st, unsigned long long seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) == seq) return RDX_OK;
+        _mm_pause();
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (__atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) != seq)
+        return fail(RDX_ERR_HIP, "internal: the search completed without publishing its mailbox");
+    return RDX_OK;
+}
+
 // depth 0 = the caller's batch; depth 1 = the second-chance batch of queries whose candidate segments overflowed
 static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k, const uint32_t* d_allow, float* d_score,
                         int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth = 0,
                         HostOut* ho = nullptr) {
-    auto copy_out = [&]() -> int {
-        if (!ho) return RDX_OK;
-        if (k > 0) {
-            HIP_TRY(hipMemcpyAsync(ho->score, d_score, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(ho->row, d_row, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-        }
-        HIP_TRY(hipMemcpyAsync(ho->count, d_count, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-        return RDX_OK;
-    };
     const int nq_pad = (int)((nq + 255) / 256 * 256);
-    const bool prof = h->profile != 0 && depth == 0;
+    const bool prof_all = h->profile == 1 && depth == 0, prof_main = h->profile != 0 && depth == 0;
     auto mark = [&](int i) {
-        if (prof) (void)hipEventRecord(h->ev[i], st);
+        if (prof_all || (prof_main && (i == 3 || i == 4))) (void)hipEventRecord(h->ev[i], st);
     };
     // K1 on the queries: qhat (fp32, exact re-score) + tiled fp16 copy (scan)
     RDX_TRY(h->qhat.ensure((size_t)nq_pad * h->dim * 4));
@@ -604,9 +659,14 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     static_assert(sizeof(RefineCounters) <= SIB_OFF, "counter block layout");
     RDX_TRY(h->ctr.ensure(SIB_OFF + SIB_BYTES));
     RDX_TRY(h->exact_list.ensure((size_t)nq_pad * 4));
+    RDX_TRY(ensure_mailbox(h));
+    if (!h->ctr_ready) {   // zeroed once; afterwards the k_finish of every search leaves it zeroed for the next one
+        HIP_TRY(hipMemsetAsync(h->ctr.p, 0, SIB_OFF + SIB_BYTES, st));
+        h->ctr_ready = true;
+    }
     int* d_bad = reinterpret_cast<int*>(h->ctr.as<char>() + offsetof(RefineCounters, bad));
+    const unsigned long long seq = ++h->seq;
     mark(0);
-    HIP_TRY(hipMemsetAsync(h->ctr.p, 0, SIB_OFF + SIB_BYTES, st));   // the only memset of a search (counters, NaN flag, sibling progress)
     hipLaunchKernelGGL(k_normalize<true>, dim3((int)((nq_pad + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
                        (const int64_t*)nullptr, (int64_t)0, h->qhat.as<float>(), h->qshadow.as<_Float16>(), h->ksteps, h->scale(),
                        d_bad, (int64_t)nq_pad);
@@ -618,9 +678,9 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     //  cost and then streams fp16 at > 6 TB/s, so it wins from ~64 K rows even for a single query)
     const bool small = h->rows < 2048 || (h->rows < 65536 && nq * h->rows <= (int64_t)1 << 22);
     const bool exact_only = h->force_exact || k > K_FAST_MAX || k == 0 || h->rows < 1 || (small && !h->force_fast);
-    int n_exact = 0;
-    RefineCounters ctr = {};
     int64_t sample_rows = 0;
+    int grid = 0, G = 0, nqt = 0;
+    bool balance = false;
     if (exact_only) {
         for (int i = 2; i <= 5; ++i) mark(i);
         if ((size_t)nq_pad * 4 > h->iota.bytes) {   // identity query list, uploaded once (grow-only), not per search
@@ -632,17 +692,13 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             HIP_TRY(hipStreamSynchronize(st));
         }
         RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st));
-        RDX_TRY(copy_out());
-        HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        n_exact = (int)nq;
     } else {
         const int bn = nq <= 64 ? 64 : (nq <= 128 ? 128 : 256);
-        const int nqt = (int)((nq + bn - 1) / bn);
-        const int grid = std::max(8, h->n_cu / 8 * 8);
+        nqt = (int)((nq + bn - 1) / bn);
+        grid = std::max(8, h->n_cu / 8 * 8);
         const int wpx = grid / 8;
         if (nqt > wpx) return fail(RDX_ERR_STATE, "internal: query chunk larger than one scan launch");
-        const int G = wpx / nqt;
+        G = wpx / nqt;
         const int n_streams = 8 * G;
         if (n_streams > REFINE_STREAMS) return fail(RDX_ERR_STATE, "internal: more streams than the refine kernel gathers");
         const int n_sets = n_streams * SETS_PER_STREAM;
@@ -690,6 +746,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         RDX_TRY(h->sib_scratch.ensure((size_t)REFINE_STREAMS * 16 * 8));
         p.sib_scratch = h->sib_scratch.as<uint8_t>();
         p.sib = (nqt > 1 && nqt <= 16 && h->ksteps >= 4 && h->sib_sync) ? reinterpret_cast<uint32_t*>(h->ctr.as<char>() + SIB_OFF) : nullptr;
+        if (p.sib) HIP_TRY(hipMemsetAsync(h->ctr.as<char>() + SIB_OFF, 0, SIB_BYTES, st));   // sibling progress bytes (option sib_sync only)
 
         p.tile_stride = div;
         RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn, res, p, grid, st));
@@ -703,7 +760,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         // first of 16.5, always the same ones). Each XCD therefore gets a contiguous range of the tile schedule sized by
         // its speed in the previous main scans (from the workgroups' own time stamps, damped) — no coordination
         // inside the kernel, just a different static split. Large launches only.
-        const bool balance = h->xcd_balance && depth == 0 && n_tiles >= 1024 && grid <= 512;
+        balance = h->xcd_balance && depth == 0 && n_tiles >= 1024 && grid <= 512;
         if (balance) {
             RDX_TRY(h->wgt.ensure((size_t)grid * 16));
             p.use_xlo = 1;
@@ -723,7 +780,6 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             p.xlo[8] = (int)n_tiles;
         }
         RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, res, p, grid, st));
-        if (balance) HIP_TRY(hipMemcpyAsync(h->wg_times, h->wgt.p, (size_t)grid * 16, hipMemcpyDeviceToHost, st));
         p.use_xlo = 0;
         p.wgt = nullptr;
         mark(4);
@@ -739,17 +795,46 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             HIP_TRY(hipGetLastError());
         }
         mark(5);
-        RDX_TRY(copy_out());
-        HIP_TRY(hipMemcpyAsync(&ctr, h->ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        n_exact = ctr.n_exact;
+    }
+    // K6: results of small host calls -> pinned staging, counters (+ workgroup stamps) -> mailbox, counter block re-zeroed
+    const size_t b_s = (size_t)nq * k * 4, b_r = (size_t)nq * k * 8, b_c = (size_t)nq * 4;
+    const bool ride = ho && b_s + b_r + b_c <= PIN_MAX;
+    if (ride) RDX_TRY(ensure_pin_out(h, b_s + b_r + b_c));
+    if (ho && !ride) {
+        if (k > 0) {
+            HIP_TRY(hipMemcpyAsync(ho->score, d_score, b_s, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(ho->row, d_row, b_r, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipMemcpyAsync(ho->count, d_count, b_c, hipMemcpyDeviceToHost, st));
+    }
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, st, h->ctr.as<RefineCounters>(), h->mbox_dev, seq,
+                       balance ? h->wgt.as<unsigned long long>() : (const unsigned long long*)nullptr, balance ? 2 * grid : 0,
+                       reinterpret_cast<const uint32_t*>(d_row), reinterpret_cast<uint32_t*>(h->pin_out_dev), (int64_t)(ride ? b_r / 4 : 0),
+                       reinterpret_cast<const uint32_t*>(d_score), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r), (int64_t)(ride ? b_s / 4 : 0),
+                       reinterpret_cast<const uint32_t*>(d_count), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r + b_s), (int64_t)(ride ? b_c / 4 : 0));
+    HIP_TRY(hipGetLastError());
+    if (ho && !ride) HIP_TRY(hipStreamSynchronize(st));   // pageable D2H copies: complete only after a stream synchronise
+    RDX_TRY(wait_search(h, st, seq));   // the ONE host wait of a search
+    const Mailbox& mb = *h->mbox;
+    const unsigned long long c_emitted = mb.emitted, c_rescored = mb.rescored;
+    const int c_bad = mb.bad;
+    int n_exact = exact_only ? (int)nq : mb.n_exact;
+    if (ride) {
+        if (k > 0) {
+            std::memcpy(ho->row, h->pin_out, b_r);
+            std::memcpy(ho->score, h->pin_out + b_r, b_s);
+        }
+        std::memcpy(ho->count, h->pin_out + b_r + b_s, b_c);
+    }
+    if (!exact_only) {
         if (n_exact > 0 && ho) ho->stale = true;   // a fallback pass rewrites some of the rows copied above
         if (balance) {   // the stamps arrived with the counters: re-weight the XCD shares for the next search
+            const unsigned long long* wt = mb.wg_times;
             unsigned long long t0 = ~0ull, tx[8] = {};
             for (int b = 0; b < grid; ++b) {
                 if ((b >> 3) >= G * nqt) continue;   // idle workgroups (wpx % nqt != 0) return before they stamp
-                t0 = std::min(t0, h->wg_times[2 * b]);
-                tx[b & 7] = std::max(tx[b & 7], h->wg_times[2 * b + 1]);
+                t0 = std::min(t0, wt[2 * b]);
+                tx[b & 7] = std::max(tx[b & 7], wt[2 * b + 1]);
             }
             double dur[8], mean = 0;
             for (int x = 0; x < 8; ++x) mean += (dur[x] = (double)(tx[x] - t0)) / 8.0;
@@ -766,7 +851,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
                 for (int x = 0; x < 8; ++x) h->xw[x] *= 8.0 / sum;
             }
         }
-        if (n_exact > 0 && depth == 0 && h->retry) {
+        if (n_exact > 0 && !c_bad && depth == 0 && h->retry) {
             // Overflow means "far more rows above the sampled threshold than expected": similar rows stored together
             // (chunks of one document) that the sparse sample missed. Before paying the exact full scan (one fp32 pass over
             // the corpus per 4 queries), give exactly these queries one more MFMA pass as a small, HBM-bound batch with a
@@ -787,27 +872,28 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             hipLaunchKernelGGL(k_scatter_topk, dim3(m), dim3(64), 0, st, h->r_s.as<float>(), h->r_r.as<int64_t>(), h->r_c.as<int32_t>(),
                                h->r_list.as<int32_t>(), m, k, d_score, d_row, d_count);
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));   // rdx_search returns with the stream drained
             acc_stats->retried_queries += m;
             acc_stats->emitted += sub.emitted;
             acc_stats->rescored += sub.rescored;
             n_exact = (int)sub.exact_queries;
-        } else if (n_exact > 0) {
+        } else if (n_exact > 0 && !c_bad) {
             RDX_TRY(run_exact(h, h->exact_list.as<int32_t>(), n_exact, k, d_allow, d_score, d_row, d_count, st));
+            HIP_TRY(hipStreamSynchronize(st));
         }
         acc_stats->scan_main_launch_rows = h->rows;
         acc_stats->scan_main_launch_queries = nq;
     }
     mark(6);
-    // one host synchronisation per search (the counter block read back after K4, above); it also carried the NaN flag
-    if (ctr.bad) return fail(RDX_ERR_INVALID, "query embeddings contain NaN or Inf");
-    if (prof) HIP_TRY(hipEventSynchronize(h->ev[6]));
+    if (c_bad) return fail(RDX_ERR_INVALID, "query embeddings contain NaN or Inf");
+    if (prof_all) HIP_TRY(hipEventSynchronize(h->ev[6]));
 
     acc_stats->sample_rows += exact_only ? 0 : sample_rows;
-    acc_stats->emitted += (int64_t)ctr.emitted;
-    acc_stats->rescored += (int64_t)ctr.rescored;
+    acc_stats->emitted += (int64_t)c_emitted;
+    acc_stats->rescored += (int64_t)c_rescored;
     acc_stats->exact_queries += n_exact;
     acc_stats->path = exact_only ? 1 : 0;
-    if (prof) {
+    if (prof_all) {
         float ms[6] = {};
         for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]);
         acc_stats->profiled = 1;
@@ -820,6 +906,11 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         float tot = 0;
         (void)hipEventElapsedTime(&tot, h->ev[0], h->ev[6]);
         acc_stats->ms_total += tot;
+    } else if (prof_main && !exact_only) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->ev[3], h->ev[4]);   // both completed: the mailbox came after them in the stream
+        acc_stats->profiled = 2;
+        acc_stats->ms_scan_main += ms;
     }
     return RDX_OK;
 }

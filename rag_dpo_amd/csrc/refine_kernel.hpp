@@ -16,6 +16,44 @@ struct RefineCounters {   // one per index, zeroed before every search
     int bad;              // set by K1 when a query embedding holds NaN/Inf
 };
 
+// What the LAST kernel of a search leaves in pinned host memory (written straight over PCIe, no memcpy, no interrupt):
+// the host spins on `seq` instead of paying a D2H copy plus hipStreamSynchronize (~25 us of a 0.1 ms search).
+struct Mailbox {
+    unsigned long long seq;            // written last, system-scope release: search number `seq` is complete
+    unsigned long long emitted, rescored;
+    int n_exact, bad;
+    unsigned long long wg_times[1024]; // [grid][2] start/end stamps of the main scan's workgroups (XCD balancing)
+};
+
+// K6. End of every search: (1) small results of HOST callers go from the device result buffers to pinned host staging,
+// (2) the counters (and the workgroup stamps) go to the mailbox, (3) the counter block is zeroed for the next search
+// (searches on one index are serialised by its mutex and each one has completed before the next is enqueued),
+// (4) the sequence number is published. One block: the volumes are KBs.
+__global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ctr, Mailbox* __restrict__ mb, unsigned long long seq,
+                                                const unsigned long long* __restrict__ wgt, int n_wgt,
+                                                const uint32_t* __restrict__ s0, uint32_t* __restrict__ d0, int64_t w0,
+                                                const uint32_t* __restrict__ s1, uint32_t* __restrict__ d1, int64_t w1,
+                                                const uint32_t* __restrict__ s2, uint32_t* __restrict__ d2, int64_t w2) {
+    for (int64_t i = threadIdx.x; i < w0; i += blockDim.x) d0[i] = s0[i];
+    for (int64_t i = threadIdx.x; i < w1; i += blockDim.x) d1[i] = s1[i];
+    for (int64_t i = threadIdx.x; i < w2; i += blockDim.x) d2[i] = s2[i];
+    for (int i = threadIdx.x; i < n_wgt; i += blockDim.x) mb->wg_times[i] = wgt[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mb->emitted = ctr->emitted;
+        mb->rescored = ctr->rescored;
+        mb->n_exact = ctr->n_exact;
+        mb->bad = ctr->bad;
+        ctr->emitted = 0;
+        ctr->rescored = 0;
+        ctr->n_exact = 0;
+        ctr->bad = 0;
+        __threadfence_system();
+        __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // One block per query (256 threads, 1024 when k is large: the exact re-score runs one wave per candidate row).
 //   The scan left, per (query, stream), cntw hits in a segment of capw slots: (coarse score, row) of every allowed row
 //   whose coarse score >= tau[q]. They are gathered into LDS; c_k = k-th largest coarse score. Every true top-k row has
