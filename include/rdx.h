@@ -99,7 +99,9 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * the same corpus tiles for different query tiles (less fabric traffic for ~2-3 % of the throughput while the
  * launch is MFMA-bound; speed and traffic only, never results); "xcd_balance" 0/1 (default 1): the main scan's
  * tiles are split between the 8 XCDs by their measured speed in the previous searches instead of evenly (the XCDs of
- * one chip differ by up to 10 %; speed only); "retry" 0/1 (default 1): queries whose candidate
+ * one chip differ by up to 10 %; speed only); "fuse_epilogue" 0/1 (default 0): B > 128 main scan variant whose per-tile emit check rides inside the
+ * first k-step of the next tile instead of interrupting the MFMA stream (speed only; measured equal to 1 % slower);
+ * "retry" 0/1 (default 1): queries whose candidate
  * segments overflow get a second MFMA pass as a small batch (denser threshold sample) before the exact full scan. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);
 

@@ -67,13 +67,14 @@ def parse_resources(remarks: str) -> dict:
     return out
 
 
-def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and is_fresh() and not extra_flags:
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """out: build a VARIANT (extra_flags) to this path; the product library and its resource record are left alone"""
+    if out is None and not force and is_fresh() and not extra_flags:
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wall", "-Wno-unused-function", "-Rpass-analysis=kernel-resource-usage", *extra_flags]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    tmp = LIB + ".tmp"
+    tmp = (out or LIB) + ".tmp"
     cmd += ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
@@ -88,6 +89,9 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str
         os.remove(tmp)
         raise RuntimeError("scan kernels spill registers — refused (inline-asm loads may be in flight to a spilled register):\n" +
                            "\n".join(f"  {k}: {v}" for k, v in bad.items()))
+    if out is not None:
+        os.replace(tmp, out)
+        return out
     os.replace(tmp, LIB)
     res["_build"] = {"source_sha256": source_hash(), "lib_size": os.path.getsize(LIB), "flags": list(extra_flags)}
     with open(RESOURCES, "w") as f:

@@ -97,7 +97,7 @@ struct rdx_index {
     std::mutex mu;
 
     // options
-    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1;
+    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 0;
     double xw[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // relative speed of the XCDs as the last main scans showed it (sum 8)
     unsigned long long wg_times[1024] = {};    // start/end stamps of the last main scan's workgroups (host copy)
     int sample_div = 64;
@@ -282,6 +282,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "force_fast") h->force_fast = value != 0;
     else if (n == "sib_sync") h->sib_sync = value != 0;
     else if (n == "retry") h->retry = value != 0;
+    else if (n == "fuse_epilogue") h->fuse_epilogue = value != 0;
     else if (n == "xcd_balance") {
         h->xcd_balance = value != 0;
         for (double& w : h->xw) w = 1.0;
@@ -539,11 +540,11 @@ static int ensure_dynamic_lds(rdx_index* h, const void* func, size_t bytes) {
     return RDX_OK;
 }
 
-template <int BN, int EPI, bool RES, bool SIBT = false, bool NTT = false>
+template <int BN, int EPI, bool RES, bool SIBT = false, bool NTT = false, bool FUSED = false>
 static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t st) {
     // LDS: query-image ring (or the whole resident query tile) + BN hit counters + BN thresholds
     const size_t lds = (size_t)(RES ? p.ksteps : RING_SLOTS) * BN * BK * 2 + BN * 8;
-    void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES, SIBT, NTT> : k_scan<BN, EPI, false, RES, SIBT, NTT>;
+    void (*kern)(const ScanParams) = p.allow ? k_scan<BN, EPI, true, RES, SIBT, NTT, FUSED> : k_scan<BN, EPI, false, RES, SIBT, NTT, FUSED>;
     RDX_TRY(ensure_dynamic_lds(h, (const void*)kern, lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, p);
     HIP_TRY(hipGetLastError());
@@ -554,9 +555,18 @@ template <int EPI>
 static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, int grid, hipStream_t st) {
     if (bn == 64) return res ? launch_scan<64, EPI, true>(h, p, grid, st) : launch_scan<64, EPI, false>(h, p, grid, st);
     if (bn == 128) return launch_scan<128, EPI, false>(h, p, grid, st);
-    if (EPI == EPI_EMIT && p.sib) return launch_scan<256, EPI, false, EPI == EPI_EMIT>(h, p, grid, st);
-    if (p.nqt == 1) return launch_scan<256, EPI, false, false, true>(h, p, grid, st);   // one query tile: corpus read once -> nt loads
-    return launch_scan<256, EPI, false>(h, p, grid, st);
+    if constexpr (EPI == EPI_EMIT) {
+        // option fuse_epilogue (off: measured equal to -1 %): with an even number of k-steps per tile the emit
+        // check of a tile rides with the first k-step of the next one
+        const bool fused = (p.ksteps & 1) == 0 && h->fuse_epilogue;
+        if (p.sib) return fused ? launch_scan<256, EPI, false, true, false, true>(h, p, grid, st) : launch_scan<256, EPI, false, true>(h, p, grid, st);
+        if (p.nqt == 1)   // one query tile: corpus read once -> nt loads
+            return fused ? launch_scan<256, EPI, false, false, true, true>(h, p, grid, st) : launch_scan<256, EPI, false, false, true>(h, p, grid, st);
+        return fused ? launch_scan<256, EPI, false, false, false, true>(h, p, grid, st) : launch_scan<256, EPI, false>(h, p, grid, st);
+    } else {
+        if (p.nqt == 1) return launch_scan<256, EPI, false, false, true>(h, p, grid, st);
+        return launch_scan<256, EPI, false>(h, p, grid, st);
+    }
 }
 
 static const int K_FAST_MAX = 256;   // larger k goes through the exact full scan
@@ -565,7 +575,7 @@ static const int K_FAST_MAX = 256;   // larger k goes through the exact full sca
 static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, const uint32_t* d_allow, float* d_score,
                      int64_t* d_row, int32_t* d_count, hipStream_t st) {
     RDX_TRY(h->dense.ensure((size_t)QX * std::max<int64_t>(h->rows, 1) * 4));
-    const int grid_rows = (int)std::min<int64_t>((h->rows + 3) / 4, (int64_t)h->n_cu * 8);
+    const int grid_rows = (int)std::min<int64_t>((h->rows + 3) / 4, (int64_t)h->n_cu * 16);   // one row per wave up to 16 Ki rows
     for (int j0 = 0; j0 < n_list; j0 += QX) {
         const int nq = std::min(QX, n_list - j0);
         if (h->rows > 0) {
@@ -720,7 +730,9 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         // (nq_pad * n_streams is 65,536 whatever the batch: 1024 slots = 512 MiB, 4096 = 2 GiB of the 288)
         uint32_t capw = depth > 0 ? 4096 : 1024;
         while (capw < 4096 && capw < 8.0 * exp_hits) capw *= 2;
-        if (h->cand_cap && depth == 0) capw = (uint32_t)std::min<int64_t>(h->cand_cap, 1 << 16);
+        if (h->cand_cap && depth == 0) capw = (uint32_t)std::min<int64_t>(h->cand_cap, 8191);
+        // the scan addresses candidate slots with 32-bit indices (scan_kernel.hpp emit_block)
+        if ((uint64_t)nq_pad * (uint64_t)n_streams * capw >= (1ull << 29)) return fail(RDX_ERR_STATE, "internal: candidate segments exceed the 32-bit slot index");
         RDX_TRY(h->tau.ensure((size_t)nq_pad * 4));
         RDX_TRY(h->cntw.ensure((size_t)nq_pad * n_streams * 4));
         RDX_TRY(h->cand.ensure((size_t)nq_pad * n_streams * capw * 8));
@@ -743,6 +755,8 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         p.capw = capw;
         p.inv_scale2 = std::ldexp(1.0f, -2 * h->scale_log2);
         p.sib_lag = h->sib_lag;
+        p.shadow_bytes = (int64_t)shadow_bytes(h, h->cap);
+        p.oob = reinterpret_cast<int*>(h->ctr.as<char>() + offsetof(RefineCounters, oob));
         RDX_TRY(h->sib_scratch.ensure((size_t)REFINE_STREAMS * 16 * 8));
         p.sib_scratch = h->sib_scratch.as<uint8_t>();
         p.sib = (nqt > 1 && nqt <= 16 && h->ksteps >= 4 && h->sib_sync) ? reinterpret_cast<uint32_t*>(h->ctr.as<char>() + SIB_OFF) : nullptr;
@@ -818,6 +832,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     const Mailbox& mb = *h->mbox;
     const unsigned long long c_emitted = mb.emitted, c_rescored = mb.rescored;
     const int c_bad = mb.bad;
+    if (mb.oob) return fail(RDX_ERR_STATE, "internal: the scan computed a corpus address outside the scan copy (RDX_CHECK_BOUNDS build)");
     int n_exact = exact_only ? (int)nq : mb.n_exact;
     if (ride) {
         if (k > 0) {

@@ -5,8 +5,8 @@
 //   shadow  fp16 "scan copy", value = master * 2^scale_log2, stored in MFMA FRAGMENT ORDER:
 //           [row block rb = row/32][k chunk c = k/32][row half m][lane 0..63][8 halfs]
 //           lane l of chunk (rb, c, m) holds row rb*32 + m*16 + (l & 15), k = c*32 + 8*(l >> 4) + 0..7 — exactly the A
-//           operand of v_mfma_f32_16x16x32_f16 (RDX_MFMA16 = 0 builds use the 32x32x16 order instead:
-//           [rb][k/16][lane], row rb*32 + (l & 31), k = 16*(k/16) + 8*(l >> 5) + 0..7).
+//           operand of v_mfma_f32_16x16x32_f16 (same cycles per flop as the 32x32x16 shape, but the chip holds a higher clock
+//           under it, MI355X_MICROARCH.md "DVFS give-back" item 7: +4.5 % on the B = 1024 scan, measured in round 1).
 //           One chunk = 1 KiB = one fully coalesced global_load_dwordx4 of a wavefront, and all chunks of a 32-row block
 //           are contiguous (dim_pad/16 KiB): a wave streams its rows straight from HBM into VGPRs, no LDS, no address
 //           arithmetic beyond "+1 KiB".
@@ -25,14 +25,6 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef RDX_MFMA16
-// 1 (default): the scan uses v_mfma_f32_16x16x32_f16; 0: v_mfma_f32_32x32x16_f16. Same cycles per flop, but the chip
-// holds a higher clock on the 16x16x32 shape under this load (MI355X_MICROARCH.md "DVFS give-back" item 7): measured
-// +4.5 % on the B = 1024 scan end to end (same box, interleaved runs of the two builds). The two shapes want different fragment
-// orders of the corpus scan copy, so the switch is compile-time.
-#define RDX_MFMA16 1
-#endif
-
 constexpr int TILE_ROWS = 256;                    // corpus rows per scan tile / shadow block
 constexpr int BK = 64;                            // k elements per k-step image
 constexpr int KSTEP_BYTES = TILE_ROWS * BK * 2;   // 32 KiB
@@ -40,19 +32,11 @@ constexpr int MAX_DIM = 4096;
 
 // offset (in halfs) of element (row r, column k) inside the fragment-ordered corpus scan copy
 __host__ __device__ inline int64_t corpus_off(int64_t r, int k, int ksteps) {
-#if RDX_MFMA16
     // 16x16x32 A operand: chunk (rb, c = k/32, m = row half): lane l = row m*16 + (l & 15), k = c*32 + 8*(l >> 4) + 0..7
-    {
-        const int64_t rb16 = r >> 5;
-        const int m = (int)((r >> 4) & 1), c = k >> 5;
-        const int lane16 = (int)(r & 15) + (((k & 31) >> 3) << 4);
-        return (((rb16 * (ksteps * 2) + c) * 2 + m) * 64 + lane16) * 8 + (k & 7);
-    }
-#endif
-    const int64_t rb = r >> 5;
-    const int kc = k >> 4;
-    const int lane = (int)(r & 31) + (((k & 15) >> 3) << 5);
-    return ((rb * (ksteps * 4) + kc) * 64 + lane) * 8 + (k & 7);
+    const int64_t rb16 = r >> 5;
+    const int m = (int)((r >> 4) & 1), c = k >> 5;
+    const int lane16 = (int)(r & 15) + (((k & 31) >> 3) << 4);
+    return (((rb16 * (ksteps * 2) + c) * 2 + m) * 64 + lane16) * 8 + (k & 7);
 }
 
 // offset (in halfs) of element (query r, column k) inside the tiled + swizzled query scan copy
@@ -81,20 +65,19 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// k-th largest key among n keys (1 <= k <= n) by MSB-first 8-bit radix passes; all threads of the block
-// call it. hist: 256 words of LDS, bc: 4 words of LDS. Returns the key; *n_gt = #keys strictly greater.
-template <class KeyAt>
-__device__ uint32_t block_kth_largest(KeyAt key_at, int64_t n, int64_t k, uint32_t* hist, uint32_t* bc,
-                                      int64_t* n_gt) {
+// k-th largest key among the keys a block holds (1 <= k <= number of keys) by MSB-first 8-bit radix passes; all threads
+// of the block call it. `scan(f)` calls f(key) for every key THIS thread owns (from global memory, LDS or registers).
+// hist: 256 words of LDS, bc: 4 words of LDS. Returns the key; *n_gt = #keys strictly greater.
+template <class Scan>
+__device__ uint32_t block_kth_largest_scan(Scan scan, int64_t k, uint32_t* hist, uint32_t* bc, int64_t* n_gt) {
     uint32_t prefix = 0, pmask = 0;
     int64_t remaining = k, gt = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t key = key_at(i);
+        scan([&](uint32_t key) {
             if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
+        });
         __syncthreads();
         // bin where the count taken from the top reaches `remaining`: wave 0, lane l owns bins 4l..4l+3, suffix sums by
         // shuffles, crossing lane by ballot (the counts are < 2^32 here; remaining <= n)
@@ -132,6 +115,16 @@ __device__ uint32_t block_kth_largest(KeyAt key_at, int64_t n, int64_t k, uint32
     }
     *n_gt = gt;
     return prefix;
+}
+
+// the same over n keys addressed by index (key_at(i), i < n): thread t takes i = t, t + blockDim, ...
+template <class KeyAt>
+__device__ uint32_t block_kth_largest(KeyAt key_at, int64_t n, int64_t k, uint32_t* hist, uint32_t* bc, int64_t* n_gt) {
+    return block_kth_largest_scan(
+        [&](auto f) {
+            for (int64_t i = threadIdx.x; i < n; i += blockDim.x) f(key_at(i));
+        },
+        k, hist, bc, n_gt);
 }
 
 }  // namespace rdx

@@ -14,6 +14,8 @@ struct RefineCounters {   // one per index, zeroed before every search
     unsigned long long rescored;
     int n_exact;          // queries handed to the exact full scan
     int bad;              // set by K1 when a query embedding holds NaN/Inf
+    int oob;              // RDX_CHECK_BOUNDS builds: the scan computed a corpus address outside the scan copy
+    int pad0;
 };
 
 // What the LAST kernel of a search leaves in pinned host memory (written straight over PCIe, no memcpy, no interrupt):
@@ -22,6 +24,7 @@ struct Mailbox {
     unsigned long long seq;            // written last, system-scope release: search number `seq` is complete
     unsigned long long emitted, rescored;
     int n_exact, bad;
+    int oob, pad0;
     unsigned long long wg_times[1024]; // [grid][2] start/end stamps of the main scan's workgroups (XCD balancing)
 };
 
@@ -45,6 +48,8 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
         mb->rescored = ctr->rescored;
         mb->n_exact = ctr->n_exact;
         mb->bad = ctr->bad;
+        mb->oob = ctr->oob;
+        ctr->oob = 0;
         ctr->emitted = 0;
         ctr->rescored = 0;
         ctr->n_exact = 0;

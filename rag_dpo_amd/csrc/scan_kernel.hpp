@@ -12,7 +12,7 @@
 //           three k-steps ahead (waves 0..3 right behind the barrier, waves 4..7 a quarter step later: the two waves of
 //           a SIMD never sit in the expensive DMA issue together); when all k-steps of a 64-query tile fit (<= 128 KiB)
 //           the tile stays RESIDENT in LDS and the main loop has no DMA and no barrier at all (the HBM-bound regime).
-//   MFMA    v_mfma_f32_16x16x32_f16 (RDX_MFMA16, default; the 32x32x16 form is kept behind RDX_MFMA16=0), corpus
+//   MFMA    v_mfma_f32_16x16x32_f16 (same cycles per flop as 32x32x16, but the chip holds a higher clock on it), corpus
 //           fragment = A operand, query fragment = B operand: D[row][query] has the QUERY on the lane (col = lane & 15)
 //           and 4 corpus rows in the 4 accumulator registers of a block, so the per-query threshold is one value per
 //           lane and block and the epilogue is compare-only.
@@ -49,14 +49,21 @@ namespace rdx {
 #define RDX_EMIT_ON true
 #endif
 
-#ifndef RDX_SPREAD_DMA
-#define RDX_SPREAD_DMA 0
+#ifndef RDX_PD256
+#define RDX_PD256 1   // query-fragment groups read ahead at BN = 256 (each costs 8 VGPRs)
+#endif
+#ifndef RDX_HALF_STAGGER
+#define RDX_HALF_STAGGER 0   // 1: waves 4-7 run half a k-step behind waves 0-3 (their SIMD partners), see `step`; measured -3..-5 % at B = 1024
 #endif
 #ifndef RDX_DMA_STAGGER
 #define RDX_DMA_STAGGER 4   // wave-number mask: waves with (wave & mask) != 0 issue their query-image DMA later in the step
 #endif
 #ifndef RDX_DMA_LATE_NUM
 #define RDX_DMA_LATE_NUM 2  // late position = NG/2 + NUM*NG/8
+#endif
+
+#ifndef RDX_ZERO_C
+#define RDX_ZERO_C 0   // 1: the first MFMA of a tile takes C = 0 instead of a zeroed accumulator (un-tied destination: the register allocator then spills)
 #endif
 
 constexpr int EPI_SETMAX = 0;
@@ -89,10 +96,9 @@ struct ScanParams {
     int xlo[9];                //   [xlo[x], xlo[x+1]) (the XCDs of one chip do not run equally fast; the host sizes the ranges from the
     unsigned long long* wgt;   //   [grid][2] start / end wall_clock64 of every workgroup (NULL: not wanted)   finish times)
     int sib_lag;               // throttle when the slowest sibling looks more than this many k-steps behind (a snapshot is ~2-3 old)
+    int64_t shadow_bytes;      // RDX_CHECK_BOUNDS builds: size of the scan copy ...
+    int* oob;                  // ... and the flag a corpus read outside it raises (tests/test_gpu_bounds.py)
 };
-
-// row inside a 32x32 MFMA block held by accumulator register r of a lane in half h (= lane >> 5)
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // 16 B per lane straight into VGPRs; completion is the CALLER's business (counted s_waitcnt vmcnt)
 #ifndef RDX_NT_SMALL
@@ -101,21 +107,31 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // NT: the corpus stream of a launch with ONE query tile is read exactly once, by one workgroup -> non-temporal loads (they
 // do not displace the query images in L2 and skip the allocate; measured at 10M x 1024: B = 64 6.3 -> 6.95 TB/s, B = 1
 // 6.3 -> 7.0, B = 128 6.5 -> 6.8). With several query tiles the siblings WANT the tile in L2: plain loads.
-template <bool NT = false>
-__device__ __forceinline__ void gload16(half8& dst, const char* addr) {
-    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(addr) : "memory");
-    else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(addr) : "memory");
+// Address = wave-uniform base (SGPR pair) + 32-bit lane offset + immediate: no per-lane 64-bit address registers or adds.
+template <bool NT, int IMM>
+__device__ __forceinline__ void gload16(half8& dst, const char* base, uint32_t lane_off) {
+    if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(dst) : "v"(lane_off), "s"(base), "n"(IMM) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(lane_off), "s"(base), "n"(IMM) : "memory");
 }
 
-// all but the N newest vector-memory operations of this wave are complete; the fragments become visible to the compiler
+// a wave-uniform pointer the compiler may have parked in VGPRs: back into SGPRs for an "s" asm operand
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_keep(half8 (&a)[4]) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(N) : "memory");
 }
 
-template <int BN, int EPI, bool HAS_MASK, bool RES, bool SIBT = false, bool NTT = false>
+// FUSEDT (EMIT, BN = 256, even number of k-steps per tile — the host checks): a tile's emit check rides with the first
+// k-step of the next tile instead of interrupting the MFMA stream (see `step`).
+template <int BN, int EPI, bool HAS_MASK, bool RES, bool SIBT = false, bool NTT = false, bool FUSEDT = false>
 __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
-    constexpr int NBN = BN / 32;          // 32-query blocks per wave (a wave owns 32 rows x all BN queries)
+    constexpr bool FUSED = FUSEDT && EPI == EPI_EMIT;
     constexpr bool NT_A = RDX_NT_SMALL && (BN <= 128 || NTT);   // host: BN <= 128 launches and NTT launches have ONE query tile
     constexpr int B_BYTES = BN * BK * 2;  // one k-step image of this workgroup's queries
     constexpr int NPB = BN / 64;          // 1 KiB DMA pieces per wave per query image
@@ -148,7 +164,6 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
     const bool dma_late = (wave & RDX_DMA_STAGGER) != 0;
 
     const int n_sched = (int)((p.n_tiles + p.tile_stride - 1) / p.tile_stride);   // tiles in this launch
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         tail_first = p.xlo[xcd] + ls;
         my_tiles = bulk_it + (cnt > ls ? (cnt - ls + G - 1) / G : 0);
     }
-    auto sched_of = [&](int it_i) { return it_i < bulk_it ? stream + it_i * n_streams : tail_first + (it_i - bulk_it) * G; };
+    auto sched_of = [&](int it_i) __attribute__((always_inline)) { return it_i < bulk_it ? stream + it_i * n_streams : tail_first + (it_i - bulk_it) * G; };
     if (p.wgt && threadIdx.x == 0) p.wgt[2 * blockIdx.x] = wall_clock64();
     const int KS = p.ksteps;
     const int total = my_tiles * KS;   // k-steps of this workgroup (host keeps tiles*ksteps < 2^31)
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     const uint8_t* sib_pub = (wave == 0 && p.sib) ? reinterpret_cast<const uint8_t*>(sib_word) + (qt & 3)
                                                   : p.sib_scratch + ((stream * 16 + (qt & 15)) * 8 + wave);
     const int zero_off = 0;
-    auto sib_lag = [&](uint32_t word, int s_mine) {   // k-steps the slowest sibling of the snapshot is behind s_mine (mod 256)
+    auto sib_lag = [&](uint32_t word, int s_mine) __attribute__((always_inline)) {   // k-steps the slowest sibling of the snapshot is behind s_mine (mod 256)
         int lag = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     // query images of this tile: [ks][BN rows][128 B], rows (qt*BN)%256.. of the 256-row block qt*BN/256
     const char* qbase = reinterpret_cast<const char*>(p.qshadow) + ((int64_t)(qt * BN / 256) * KS) * KSTEP_BYTES +
                         (int64_t)((qt * BN) % 256) * 128 + wave * (NPB * 1024) + lane * 16;
-    auto issue_b = [&](int ks_i, int slot_i) {   // this wave's pieces of query image ks_i -> LDS slot slot_i
+    auto issue_b = [&](int ks_i, int slot_i) __attribute__((always_inline)) {   // this wave's pieces of query image ks_i -> LDS slot slot_i
         const char* src = qbase + (int64_t)ks_i * KSTEP_BYTES;
         char* dst = smem + slot_i * B_BYTES + wave * (NPB * 1024);
 #pragma unroll
@@ -203,12 +218,22 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     };
     // corpus fragments of (tile iteration it, k-step ks): 4 consecutive 1 KiB chunks of this wave's 32-row block
     const int64_t rb_bytes = (int64_t)KS * 4096;   // bytes of one 32-row block in the scan copy
-    auto a_src = [&](int it_i, int ks_i) -> const char* {
+    const uint32_t lane16 = (uint32_t)lane * 16;
+    auto a_src = [&](int it_i, int ks_i) __attribute__((always_inline)) -> const char* {
         const int64_t tile = (int64_t)sched_of(it_i) * p.tile_stride;
-        return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096 + lane * 16;
+#ifdef RDX_CHECK_BOUNDS
+        // test build: every corpus fragment address (prefetches of steps that do not exist included) must lie inside the
+        // scan copy; an address outside is reported and replaced, so the run ends with an error instead of a GPU fault
+        {
+            const int64_t off = (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096;
+            const bool bad = off < 0 || off + 4096 > p.shadow_bytes;
+            if (bad && lane == 0) atomicOr(p.oob, 1);
+            return uniform_ptr(reinterpret_cast<const char*>(p.shadow) + (bad ? 0 : off));
+        }
+#endif
+        return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096;   // wave-uniform
     };
 
-#if RDX_MFMA16
     // v_mfma_f32_16x16x32_f16: the wave's 32 rows are two 16-row blocks m, the queries NB16 blocks of 16; C layout
     // col = lane & 15 (query), row = (lane >> 4) * 4 + reg
     constexpr int NB16 = BN / 16;
@@ -221,45 +246,90 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
     float runmax[EPI == EPI_SETMAX ? NB16 : 1][1];
-#else
-    f32x16 acc[NBN];
-#pragma unroll
-    for (int n = 0; n < NBN; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-
-    // per-lane epilogue state
-    float runmax[EPI == EPI_SETMAX ? NBN : 1][2];
-#endif
     float* tau_s = reinterpret_cast<float*>(lcnt + BN);   // [BN] thresholds of this query tile (LDS: registers are scarce)
-    const int qcol0 = qt * BN + l31;   // query of n-block 0; n-block n is +32 n
     if constexpr (EPI == EPI_SETMAX) {
 #pragma unroll
         for (int n = 0; n < (int)(sizeof(runmax) / sizeof(runmax[0])); ++n)
 #pragma unroll
             for (int j = 0; j < (int)(sizeof(runmax[0]) / sizeof(float)); ++j) runmax[n][j] = -INFINITY;
     } else {
-#if RDX_MFMA16
         // stored [l15][n] so that one ds_read_b128 fetches the thresholds of four consecutive query blocks of a lane
         for (int i = threadIdx.x; i < BN; i += 512) tau_s[(i & 15) * (BN / 16) + (i >> 4)] = p.tau[qt * BN + i];
-#else
-        for (int i = threadIdx.x; i < BN; i += 512) tau_s[i] = p.tau[qt * BN + i];   // visible after the prologue barrier
-#endif
     }
 
-    // LDS address of this lane's query fragment for k sub-step kk (n-block n adds n*4096): row l31, chunk 2kk+half, swizzled
-#if RDX_MFMA16
+    // LDS address of this lane's query fragment for k sub-step kk (16-query block n adds n*2048), swizzled:
     // 16x16x32: row l15 of the 16-query block, 16-B chunk 4*kk32 + lq of the 64-k image row
     const int b_sw = ((((qt * BN) % 256) + l15) >> 1) & 7;
     int b_off[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) b_off[kk] = l15 * 128 + (((kk * 4 + lq) ^ b_sw) << 4);
-#else
-    const int b_sw = ((((qt * BN) % 256) + l31) >> 1) & 7;   // identical for every n-block (32 rows = 4 swizzle periods)
-    int b_off[4];
+
+    // ---- per-tile epilogue pieces -----------------------------------------------------------------------------------
+    // which rows of this wave's 32-row block of schedule entry it_done may be used (ragged last tile, `where` bitmap)
+    auto tile_rows = [&](int it_done, int64_t& row_b, uint32_t& okbits, bool& filt) __attribute__((always_inline)) {
+        const int64_t tile = (int64_t)sched_of(it_done) * p.tile_stride;
+        row_b = tile * TILE_ROWS + wave * 32;                  // first row of this wave's 32-row block
+        const bool ragged = (tile + 1) * TILE_ROWS > p.rows;   // tile holds padding rows
+        okbits = 0xffffffffu;                                  // bit i: row row_b+i may be used
+        if (ragged) {
+            const int64_t left = p.rows - row_b;
+            okbits = left >= 32 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << left) - 1u));
+        }
+        if constexpr (HAS_MASK) {
+            if (row_b < p.rows) okbits &= p.allow[row_b >> 5];
+        }
+        filt = HAS_MASK || ragged;
+    };
+    // EMIT: does query block n (16 queries on the lanes' columns, 32 rows in the 8 accumulator registers) hold a hit?
+    auto block_max = [&](int n) __attribute__((always_inline)) {
+        float mx = fmaxf(acc[0][n][0], acc[1][n][0]);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) b_off[kk] = l31 * 128 + (((kk * 2 + half) ^ b_sw) << 4);
-#endif
+        for (int r = 1; r < 4; ++r) mx = fmaxf(mx, fmaxf(acc[0][n][r], acc[1][n][r]));
+        return mx;
+    };
+    // EMIT, rare path (a handful of blocks per tile): append the hits of block n to the (query, stream) segments. Slot from an
+    // LDS counter (inline asm: next to LDS-DMA the compiler would put s_waitcnt vmcnt(0) in front of an LDS atomic and drain
+    // the prefetch pipeline on every hit), 8-byte fire-and-forget store.
+    uint2* const cand_s = p.cand;
+    const uint32_t capw_s = p.capw;
+    auto emit_block = [&](int n, float tq, int it_done) __attribute__((always_inline)) {
+        int64_t row_b;
+        uint32_t okbits;
+        bool filt;
+        tile_rows(it_done, row_b, okbits, filt);
+        // Everything this path needs is derived from two lane values made opaque HERE: otherwise the compiler computes the
+        // 16 per-block query indices and the 8 row-bit masks once per kernel as loop invariants — 30 VGPRs the MFMA loop
+        // does not have (they ended up in scratch).
+        int lc = l15, lr = lq * 4;
+        asm volatile("" : "+v"(lc), "+v"(lr));
+        const int ql = n * 16 + lc;
+        // candidate slot index in 32 bits (the host keeps nq_pad * n_streams * capw below 2^29 for this kernel): the
+        // store address is an SGPR base + a 32-bit lane offset, no 64-bit vector arithmetic
+        const uint32_t seg0 = ((uint32_t)(qt * BN + ql) * (uint32_t)n_streams + (uint32_t)stream) * capw_s;
+        const uint32_t row0 = (uint32_t)row_b + (uint32_t)lr;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[m][n][r];
+                if (v >= tq && (!filt || ((okbits >> (m * 16 + r + lr)) & 1u))) {
+                    uint32_t pos;
+                    const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&lcnt[ql]);
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(lds_addr), "v"(1u) : "memory");
+                    if (pos < capw_s) cand_s[seg0 + pos] = make_uint2(__float_as_uint(v * p.inv_scale2), row0 + (uint32_t)(m * 16 + r));
+                }
+            }
+    };
+    // thresholds of this lane's query column for blocks n0..n0+3 (one ds_read_b128; stored [l15][block])
+    auto tau_quad = [&](int n0) __attribute__((always_inline)) {
+        int t = l15 * NB16 + n0;
+        asm volatile("" : "+v"(t));   // not a loop invariant worth a register
+        return *reinterpret_cast<const f32x4*>(tau_s + t);
+    };
+    // this lane's threshold for block n: ONE address register per step (tb, made opaque there so that it is not a loop
+    // invariant held across the whole kernel), the block is the instruction's immediate offset
+    auto tau_one = [&](int tb, int n) __attribute__((always_inline)) { return tau_s[tb + n]; };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     if (total > 0) {
         half8 a0[4], a1[4];   // corpus fragments of the even / odd k-steps in flight
@@ -272,8 +342,10 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         }
         {
             const char* s0 = a_src(0, 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) gload16<NT_A>(a0[kk], s0 + kk * 1024);
+            gload16<NT_A, 0>(a0[0], s0, lane16);
+            gload16<NT_A, 1024>(a0[1], s0, lane16);
+            gload16<NT_A, 2048>(a0[2], s0, lane16);
+            gload16<NT_A, 3072>(a0[3], s0, lane16);
         }
         int it1 = 0, ks1 = 1;
         if (ks1 == KS) { ks1 = 0; it1 = 1; }
@@ -285,8 +357,10 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         const bool have1 = total > 1;
         {
             const char* s1 = a_src(have1 ? it1 : 0, have1 ? ks1 : 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) gload16<NT_A>(a1[kk], s1 + kk * 1024);
+            gload16<NT_A, 0>(a1[0], s1, lane16);
+            gload16<NT_A, 1024>(a1[1], s1, lane16);
+            gload16<NT_A, 2048>(a1[2], s1, lane16);
+            gload16<NT_A, 3072>(a1[3], s1, lane16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the only barrier that waits for memory: every wave's prologue DMA has landed
@@ -297,29 +371,20 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         int slot_c = 0;                // ring slot of step s (= s mod 4)
         int ksb = 3 % KS;              // k-step image that step s+3 reads (issued during step s)
 
-        // The step's 4*NBN MFMAs run as NG groups of GB query blocks. The query fragments of group g+PD are read from LDS
+        // The step's 2*2*NB16 MFMAs run as NG groups of GB query blocks. The query fragments of group g+PD are read from LDS
         // right behind the first MFMA of group g into a 4-deep register ring — also ACROSS the step boundary (the last PD
         // groups of step s prefetch the first PD groups of step s+1), so the matrix pipe never drains between steps.
         // Issue order pinned with sched_barrier(0).
         constexpr int GB = 2;                        // query blocks per group
-#if RDX_MFMA16
         constexpr int NKK = 2;                       // k sub-steps of 32
-        constexpr int GPK = (BN / 16) / GB;          // groups per k sub-step
+        constexpr int GPK = NB16 / GB;               // groups per k sub-step
         constexpr int QB_BYTES = 2048;               // LDS bytes of one 16-query block
-#else
-        constexpr int NKK = 4;                       // k sub-steps of 16
-        constexpr int GPK = NBN / GB;                // groups per k sub-step
-        constexpr int QB_BYTES = 4096;               // LDS bytes of one 32-query block
-#endif
         constexpr int NG = NKK * GPK;                // groups per step (4, 8 or 16: a multiple of the register ring)
-#ifndef RDX_PD_EMIT
-#define RDX_PD_EMIT 1
-#endif
-        // groups read ahead; at BN = 256 the register file decides (the bootstrap kernel also carries its running maxima)
-        constexpr int PD = NBN >= 8 ? (RDX_MFMA16 ? (EPI == EPI_EMIT ? RDX_PD_EMIT : 1) : 2) : (NG / 2 < 3 ? NG / 2 : 3);
+        // groups read ahead; at BN = 256 the register file decides
+        constexpr int PD = BN >= 256 ? RDX_PD256 : (NG / 2 < 3 ? NG / 2 : 3);
         constexpr int NBUF = 4;
         half8 bf[NBUF][GB];
-        auto load_group = [&](const char* img, int g, half8 (&dst)[GB]) {
+        auto load_group = [&](const char* img, int g, half8 (&dst)[GB]) __attribute__((always_inline)) {
             const int kk = g / GPK, nb0 = (g % GPK) * GB;
 #pragma unroll
             for (int j = 0; j < GB; ++j) dst[j] = *reinterpret_cast<const half8*>(img + b_off[kk] + (nb0 + j) * QB_BYTES);
@@ -328,7 +393,13 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         for (int g = 0; g < PD; ++g) load_group(smem, g, bf[g]);   // step 0 reads slot 0 / k-step image 0
 
         uint32_t poll0 = 0, poll1 = 0;   // sibling snapshots in flight (even / odd steps)
-        auto step = [&](half8 (&af)[4], uint32_t& poll, int s) {
+        // One k-step. FUSE (a std::true_type tag; EMIT only): this is the FIRST k-step of a tile and the accumulators still
+        // hold the finished tile `it_prev`: its emit check runs block by block right in front of the MFMAs that start the
+        // new tile in that block's registers with C = 0 — the check's few vector instructions issue in the shadow of the
+        // matrix pipe, nothing is zeroed, and the matrix pipe never waits for an epilogue (before: all eight waves left the
+        // MFMA stream together once per tile for ~290 vector instructions; ablation: 7 % of the launch).
+        auto step = [&](auto fuse_tag, half8 (&af)[4], uint32_t& poll, int s, int it_prev) __attribute__((always_inline)) {
+            constexpr bool FUSE = decltype(fuse_tag)::value;
             // my corpus fragments of this step have landed (issued two steps ago); the V operations of the previous step
             // stay in flight. No barrier here: the query image of step s was certified by the mid-step barrier of step s-1.
             wait_vmcnt_keep<V>(af);
@@ -351,126 +422,119 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                 // half a step ago, every step: -5 %); waves 1..7 write to a scratch byte nobody reads. Plain store: the byte
                 // stays in this XCD's L2, where the siblings' sc1 (L1-bypassing) loads find it; inline asm: a volatile C++
                 // store becomes flat_store sc0 sc1 + s_waitcnt vmcnt(0).
-                if (lane == 0) asm volatile("global_store_byte %0, %1, %2" ::"v"(zero_off), "v"(s), "s"(sib_pub) : "memory");
+                if (lane == 0) asm volatile("global_store_byte %0, %1, %2" ::"v"(zero_off), "v"(s), "s"(uniform_ptr(sib_pub)) : "memory");
             }
             const int ksn = ks + 1 == KS ? 0 : ks + 1;
             const char* st = smem + (RES ? ks : slot_c) * B_BYTES;
             const char* stn = smem + (RES ? ksn : ((slot_c + 1) & 3)) * B_BYTES;   // image of step s+1
             const bool more = s + 2 < total;   // step s+2 exists; otherwise re-read this stream's first step (never used)
             const char* an = a_src(more ? it2 : 0, more ? ks2 : 0);
+            float tq_cur = 0.f;   // FUSE: this lane's threshold for the next block to check, fetched one block ahead
+            int tb = l15 * NB16;
+            if constexpr (FUSE) {
+                asm volatile("" : "+v"(tb));
+                tq_cur = tau_one(tb, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int kk = g / GPK, nb0 = (g % GPK) * GB;
                 if constexpr (!RES) {
-                    if (g == NG / 2) {
-                        // Mid-step: ONE barrier per step, and it never waits for memory in steady state. My DMA pieces of
-                        // image s+1 were issued two steps ago: 4 + V newer operations may stay in flight (A2 A3 of step s-2,
-                        // the V of step s-1, A0 A1 of this step). After the barrier every wave's pieces of image s+1 have
-                        // landed and every wave has left step s-1, whose ring slot is refilled with image s+3.
+                    // ONE barrier per step, and it never waits for memory in steady state. My DMA pieces of image s+1 were
+                    // issued two steps ago: 4 + V newer operations may stay in flight. After the barrier every wave's pieces of
+                    // image s+1 have landed and every wave has left step s-1, whose ring slot is refilled with image s+3.
+                    // RDX_HALF_STAGGER: waves 0-3 meet the barrier in the MIDDLE of their step, waves 4-7 (their SIMD partners)
+                    // at the START of theirs, i.e. the late half runs half a k-step behind its partner for the whole launch:
+                    // while one wave of a SIMD sits in wait / barrier / DMA issue / emit check, the other one is in the middle
+                    // of a pure MFMA stretch (MI355X_MICROARCH.md "Two waves per SIMD" item 9). The same counts hold for both
+                    // halves: a late wave issued its pieces of image s+1 at the start of step s-2, 4 + V operations ago.
+                    const bool here = RDX_HALF_STAGGER ? (g == 0 ? dma_late : (g == NG / 2 ? !dma_late : false)) : g == NG / 2;
+                    if ((RDX_HALF_STAGGER && (g == 0 || g == NG / 2)) || (!RDX_HALF_STAGGER && g == NG / 2)) {
                         __builtin_amdgcn_sched_barrier(0);
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + SIBN + V) : "memory");
-                        __builtin_amdgcn_s_barrier();
-#if !defined(RDX_ABL_NOB) && !RDX_SPREAD_DMA
-                        if (!RDX_DMA_STAGGER || !dma_late) issue_b(ksb, (slot_c + 3) & 3);
+                        if (here) {
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + SIBN + V) : "memory");
+                            __builtin_amdgcn_s_barrier();
+#if !defined(RDX_ABL_NOB)
+                            if (RDX_HALF_STAGGER || !RDX_DMA_STAGGER || !dma_late) issue_b(ksb, (slot_c + 3) & 3);
 #endif
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#if !defined(RDX_ABL_NOB) && !RDX_SPREAD_DMA && RDX_DMA_STAGGER
-                    // the two waves of a SIMD issue their DMA pieces a quarter step apart: while one of them sits in the
-                    // (expensive) DMA issue the other one keeps the matrix pipe fed. Same order of vector-memory operations
-                    // inside the step for every wave (A0 A1 | DMA | A2 A3), so the counted waits are unchanged.
-                    if (g == NG / 2 + RDX_DMA_LATE_NUM * NG / 8) {
+#if !defined(RDX_ABL_NOB)
+                    // (without the half-step stagger) the two waves of a SIMD issue their DMA pieces a quarter step apart
+                    if (!RDX_HALF_STAGGER && RDX_DMA_STAGGER && g == NG / 2 + RDX_DMA_LATE_NUM * NG / 8) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (dma_late) issue_b(ksb, (slot_c + 3) & 3);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#endif
-#if !defined(RDX_ABL_NOB) && RDX_SPREAD_DMA
-                    // the DMA pieces of image s+3 are spread over the second half of the step (one per DMA_EVERY groups)
-                    // instead of one burst behind the barrier: their issue cost then hides under the MFMAs of both waves
-                    constexpr int DMA_EVERY = (NG / 2) / NPB > 0 ? (NG / 2) / NPB : 1;
-                    if (g >= NG / 2 && (g - NG / 2) % DMA_EVERY == 0 && (g - NG / 2) / DMA_EVERY < NPB) {
-                        constexpr int dummy = 0; (void)dummy;
-                        const int i = (g - NG / 2) / DMA_EVERY;
-                        __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_global_load_lds(
-                            (const __attribute__((address_space(1))) void*)(qbase + (int64_t)ksb * KSTEP_BYTES + i * 1024),
-                            (__attribute__((address_space(3))) void*)(smem + ((slot_c + 3) & 3) * B_BYTES + wave * (NPB * 1024) + i * 1024),
-                            16, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #endif
                 }
 #pragma unroll
                 for (int j = 0; j < GB; ++j) {
-#if RDX_MFMA16
-                    acc[0][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk], bf[g % NBUF][j], acc[0][nb0 + j], 0, 0, 0);
-#else
-                    acc[nb0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[g % NBUF][j], acc[nb0 + j], 0, 0, 0);
+                    const int n = nb0 + j;
+                    if constexpr (FUSE) {
+                        if (kk == 0) {
+                            // the finished tile's emit check for block n, in front of the MFMAs that overwrite its registers
+                            const float mx = block_max(n);
+                            const float tq = tq_cur;
+                            if (n + 1 < NB16) tq_cur = tau_one(tb, n + 1);   // next block's threshold, one block ahead
+                            if (!RDX_EMIT_ON) asm volatile("" ::"v"(mx));   // keep the values alive in ablation builds
+                            if (RDX_EMIT_ON && __any(mx >= tq)) {
+                                emit_block(n, tq, it_prev);
+                            }
+#if !RDX_ZERO_C
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
 #endif
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (RDX_ZERO_C && FUSE && kk == 0) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bf[g % NBUF][j], zero4, 0, 0, 0);
+                    else acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk], bf[g % NBUF][j], acc[0][n], 0, 0, 0);
                     if (j == 0) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (g + PD < NG) load_group(st, g + PD, bf[(g + PD) % NBUF]);
                         else load_group(stn, g + PD - NG, bf[(g + PD) % NBUF]);   // first groups of step s+1 (after the mid barrier)
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#if RDX_MFMA16
-                    acc[1][nb0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk + 1], bf[g % NBUF][j], acc[1][nb0 + j], 0, 0, 0);
-#endif
+                    if (RDX_ZERO_C && FUSE && kk == 0) acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bf[g % NBUF][j], zero4, 0, 0, 0);
+                    else acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk + 1], bf[g % NBUF][j], acc[1][n], 0, 0, 0);
                 }
                 if ((g % GPK) == GPK - 1) {
                     __builtin_amdgcn_sched_barrier(0);
                     // the matrix pipe has read this sub-step's fragments: refill them with those of step s+2 (land during the next step)
 #if defined(RDX_ABL_NOA)   // developer ablation (tools/ab_lib.py): timing without the corpus stream, results are garbage
                     asm volatile("" ::"v"(an));
-#elif RDX_MFMA16
-                    gload16<NT_A>(af[2 * kk], an + (2 * kk) * 1024);
-                    gload16<NT_A>(af[2 * kk + 1], an + (2 * kk + 1) * 1024);
-                    if constexpr (SIB) {
-                        if (kk == 0) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(poll) : "v"(zero_off), "s"(sib_word) : "memory");
-                    }
 #else
-                    gload16<NT_A>(af[kk], an + kk * 1024);
+                    if (kk == 0) {
+                        gload16<NT_A, 0>(af[0], an, lane16);
+                        gload16<NT_A, 1024>(af[1], an, lane16);
+                    } else {
+                        gload16<NT_A, 2048>(af[2], an, lane16);
+                        gload16<NT_A, 3072>(af[3], an, lane16);
+                    }
+                    if constexpr (SIB) {
+                        if (kk == 0) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(poll) : "v"(zero_off), "s"(uniform_ptr(sib_word)) : "memory");
+                    }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         };
 
-        auto epilogue = [&](int it_done) {
-            const int64_t tile = (int64_t)sched_of(it_done) * p.tile_stride;
-            const int64_t row_b = tile * TILE_ROWS + wave * 32;   // first row of this wave's 32-row block
-            const bool ragged = (tile + 1) * TILE_ROWS > p.rows;  // tile holds padding rows
-            uint32_t okbits = 0xffffffffu;                        // bit i: row row_b+i may be used
-            if (ragged) {
-                const int64_t left = p.rows - row_b;
-                okbits = left >= 32 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << left) - 1u));
-            }
-            if constexpr (HAS_MASK) {
-                if (row_b < p.rows) okbits &= p.allow[row_b >> 5];
-            }
-            const bool filt = HAS_MASK || ragged;
-#if RDX_MFMA16
-            // thresholds of this lane's query column, four blocks per LDS read, fetched one quad ahead of their use
-            f32x4 tq4 = {0.f, 0.f, 0.f, 0.f}, tq4n = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == EPI_EMIT) {
-                int t0 = l15 * NB16;
-                asm volatile("" : "+v"(t0));   // not a loop invariant worth a register
-                tq4n = *reinterpret_cast<const f32x4*>(tau_s + t0);
-            }
+        // stand-alone epilogue of tile it_done: bootstrap maxima (SETMAX); emit check of the LAST tile of the stream and of
+        // every tile when the check cannot ride with the next tile's first step (odd number of k-steps)
+        auto epilogue = [&](int it_done) __attribute__((always_inline)) {
+            f32x4 tq4 = zero4, tq4n = zero4;
+            int64_t row_b = 0;
+            uint32_t okbits = 0xffffffffu;
+            bool filt = false;
+            if constexpr (EPI == EPI_EMIT) tq4n = tau_quad(0);
+            else tile_rows(it_done, row_b, okbits, filt);
 #pragma unroll
             for (int n = 0; n < NB16; ++n) {
-                if constexpr (EPI == EPI_EMIT) {
-                    if ((n & 3) == 0) {
-                        tq4 = tq4n;
-                        if (n + 4 < NB16) {
-                            int t1 = l15 * NB16 + n + 4;
-                            asm volatile("" : "+v"(t1));
-                            tq4n = *reinterpret_cast<const f32x4*>(tau_s + t1);
-                        }
-                    }
-                }
                 if constexpr (EPI == EPI_SETMAX) {
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
@@ -481,123 +545,77 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                             runmax[n][0] = fmaxf(runmax[n][0], v);
                         }
                 } else {
-                    float mx = fmaxf(acc[0][n][0], acc[1][n][0]);
-#pragma unroll
-                    for (int r = 1; r < 4; ++r) mx = fmaxf(mx, fmaxf(acc[0][n][r], acc[1][n][r]));
-                    int ql = n * 16 + l15;
-                    // opaque to the optimiser: otherwise the 16 per-block LDS addresses and segment pointers are hoisted out
-                    // of the tile loop as loop invariants and cost ~50 VGPRs the main loop needs
-                    asm volatile("" : "+v"(ql));
+                    if ((n & 3) == 0) {
+                        tq4 = tq4n;
+                        if (n + 4 < NB16) tq4n = tau_quad(n + 4);
+                    }
+                    const float mx = block_max(n);
                     const float tq = tq4[n & 3];
                     if (!RDX_EMIT_ON) asm volatile("" ::"v"(mx));   // keep the MFMAs alive in ablation builds
-                    if (RDX_EMIT_ON && __any(mx >= tq)) {
-                        uint2* seg = p.cand + ((int64_t)(qt * BN + ql) * n_streams + stream) * p.capw;
-#pragma unroll
-                        for (int m = 0; m < 2; ++m)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float v = acc[m][n][r];
-                                const int rib = m * 16 + lq * 4 + r;
-                                if (v >= tq && (!filt || ((okbits >> rib) & 1u))) {
-                                    uint32_t pos;
-                                    const uint32_t lds_addr =
-                                        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&lcnt[ql]);
-                                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(lds_addr), "v"(1u) : "memory");
-                                    if (pos < p.capw) seg[pos] = make_uint2(__float_as_uint(v * p.inv_scale2), (uint32_t)(row_b + rib));
-                                }
-                            }
-                    }
+                    if (RDX_EMIT_ON && __any(mx >= tq)) emit_block(n, tq, it_done);
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
             }
-#else
-#pragma unroll
-            for (int n = 0; n < NBN; ++n) {
-                if constexpr (EPI == EPI_SETMAX) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = acc[n][r];
-                        if (filt && !((okbits >> acc_row(r, half)) & 1u)) v = -INFINITY;
-                        runmax[n][r & 1] = fmaxf(runmax[n][r & 1], v);
-                    }
-                } else {
-                    float mx = acc[n][0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[n][r]);
-                    const int ql = n * 32 + l31;
-                    const float tq = tau_s[ql];
-                    if (!RDX_EMIT_ON) asm volatile("" ::"v"(mx));   // keep the MFMAs alive in ablation builds
-                    if (RDX_EMIT_ON && __any(mx >= tq)) {
-                        uint2* seg = p.cand + ((int64_t)(qt * BN + ql) * n_streams + stream) * p.capw;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = acc[n][r];
-                            const int rib = acc_row(r, half);
-                            if (v >= tq && (!filt || ((okbits >> rib) & 1u))) {
-                                // LDS counter: no global round trip. Inline asm: next to LDS-DMA the compiler would put
-                                // s_waitcnt vmcnt(0) in front of an LDS atomic and drain the prefetch pipeline on every hit.
-                                uint32_t pos;
-                                const uint32_t lds_addr =
-                                    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&lcnt[ql]);
-                                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(pos) : "v"(lds_addr), "v"(1u) : "memory");
-                                if (pos < p.capw) seg[pos] = make_uint2(__float_as_uint(v * p.inv_scale2), (uint32_t)(row_b + rib));
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-            }
-#endif
         };
 
-        auto advance = [&](int) {
+        auto advance = [&](int) __attribute__((always_inline)) {
             const bool last_k = ks == KS - 1;
             const int it_done = it;
             if (++ks == KS) { ks = 0; ++it; }
             if (++ks2 == KS) { ks2 = 0; ++it2; }
             slot_c = (slot_c + 1) & 3;
             if (++ksb == KS) ksb = 0;
-            if (last_k) epilogue(it_done);
+            if constexpr (!FUSED) {
+                if (last_k) epilogue(it_done);
+            }
         };
 
         // steps alternate between the two fragment register sets
         int s = 0;
-        for (; s + 1 < total; s += 2) {
-            step(a0, poll0, s);
-            advance(s);
-            step(a1, poll1, s + 1);
-            advance(s + 1);
-        }
-        if (s < total) {
-            step(a0, poll0, s);
-            advance(s);
+        if constexpr (FUSED) {
+            // Tile by tile (KS is even: every tile starts on the a0 register set). No branch ever chooses between two step
+            // bodies (the register allocator answers that with a second copy of the accumulators): the first tile is peeled.
+            auto pair = [&](auto first_tag, int it_prev) __attribute__((always_inline)) {
+                step(first_tag, a0, poll0, s, it_prev);
+                advance(s);
+                step(std::false_type{}, a1, poll1, s + 1, 0);
+                advance(s + 1);
+                s += 2;
+            };
+            pair(std::false_type{}, 0);
+            for (int j = 2; j < KS; j += 2) pair(std::false_type{}, 0);
+            for (int t = 1; t < my_tiles; ++t) {
+                pair(std::true_type{}, t - 1);
+                for (int j = 2; j < KS; j += 2) pair(std::false_type{}, 0);
+            }
+            epilogue(my_tiles - 1);
+        } else {
+            for (; s + 1 < total; s += 2) {
+                step(std::false_type{}, a0, poll0, s, 0);
+                advance(s);
+                step(std::false_type{}, a1, poll1, s + 1, 0);
+                advance(s + 1);
+            }
+            if (s < total) {
+                step(std::false_type{}, a0, poll0, s, 0);
+                advance(s);
+            }
         }
         // drain the never-consumed tail prefetches; naming all eight fragments keeps their registers reserved until here
-        asm volatile("s_waitcnt vmcnt(0)" ::"v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
-                     "v"(poll0), "v"(poll1)
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3])
                      : "memory");
+        if constexpr (SIB) asm volatile("" ::"v"(poll0), "v"(poll1));
     }
 
     if (p.wgt && threadIdx.x == 0) p.wgt[2 * blockIdx.x + 1] = wall_clock64();
     if constexpr (EPI == EPI_SETMAX) {
-#if RDX_MFMA16
         // set id = (stream*8 + wave)*4 + (lane >> 4) ; layout setmax[query][set]
 #pragma unroll
         for (int n = 0; n < NB16; ++n)
             p.setmax[(int64_t)(qt * BN + n * 16 + l15) * p.n_sets + (int64_t)(stream * 8 + wave) * 4 + lq] = runmax[n][0];
-#else
-        // set id = (stream*8 + wave)*4 + j*2 + half ; layout setmax[query][set]
-#pragma unroll
-        for (int n = 0; n < NBN; ++n) {
-            float* dst = p.setmax + (int64_t)(qcol0 + n * 32) * p.n_sets + (int64_t)(stream * 8 + wave) * 4 + half;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) dst[j * 2] = runmax[n][j];
-        }
-#endif
     } else {
         __syncthreads();
         for (int i = threadIdx.x; i < BN; i += 512) p.cntw[(int64_t)(qt * BN + i) * n_streams + stream] = lcnt[i];

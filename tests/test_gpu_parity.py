@@ -81,6 +81,19 @@ def test_baseline_config2(eng, oracle):
     ix.close()
 
 
+def test_fused_epilogue_variant(eng, oracle):
+    """option fuse_epilogue: the B > 128 main scan whose emit check rides in the next tile's first k-step — several tiles per
+    stream (so that the fused step runs), a ragged last tile, a row bitmap, planted near-duplicates, both against the oracle"""
+    corpus = synth.make_corpus(140_001, 256)           # 547 tiles over 64 streams: 8-9 tiles per stream; 4 k-steps per tile
+    q = synth.make_queries(300, 256, corpus)
+    ix = _index(eng, corpus, force_fast=1, fuse_epilogue=1)
+    st = _check(oracle, ix, corpus, q, 10, expect_path=0)
+    assert st["exact_queries"] == 0
+    allow = np.random.default_rng(1).random(corpus.shape[0]) < 0.4
+    _check(oracle, ix, corpus, q, 20, allow, expect_path=0)
+    ix.close()
+
+
 def test_xcd_shares_ignore_idle_workgroups(eng):
     """nq = 600 -> three query tiles: 32 workgroups per XCD = 10 streams x 3 + 2 idle ones, which return before they stamp
     their times. The XCD re-weighting must skip them (their stamp slots are stale memory): shares stay near an eighth and
