@@ -556,13 +556,23 @@ static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, i
     if (bn == 64) return res ? launch_scan<64, EPI, true>(h, p, grid, st) : launch_scan<64, EPI, false>(h, p, grid, st);
     if (bn == 128) return launch_scan<128, EPI, false>(h, p, grid, st);
     if constexpr (EPI == EPI_EMIT) {
+#ifdef RDX_CHECK_BOUNDS
+        constexpr bool HAVE_FUSED = false;   // the address-checking test build carries one more live value: no fused variants
+#else
+        constexpr bool HAVE_FUSED = true;
+#endif
         // option fuse_epilogue (off: measured equal to -1 %): with an even number of k-steps per tile the emit
         // check of a tile rides with the first k-step of the next one
-        const bool fused = (p.ksteps & 1) == 0 && h->fuse_epilogue;
-        if (p.sib) return fused ? launch_scan<256, EPI, false, true, false, true>(h, p, grid, st) : launch_scan<256, EPI, false, true>(h, p, grid, st);
-        if (p.nqt == 1)   // one query tile: corpus read once -> nt loads
-            return fused ? launch_scan<256, EPI, false, false, true, true>(h, p, grid, st) : launch_scan<256, EPI, false, false, true>(h, p, grid, st);
-        return fused ? launch_scan<256, EPI, false, false, false, true>(h, p, grid, st) : launch_scan<256, EPI, false>(h, p, grid, st);
+        if constexpr (HAVE_FUSED) {
+            if ((p.ksteps & 1) == 0 && h->fuse_epilogue) {
+                if (p.sib) return launch_scan<256, EPI, false, true, false, true>(h, p, grid, st);
+                if (p.nqt == 1) return launch_scan<256, EPI, false, false, true, true>(h, p, grid, st);
+                return launch_scan<256, EPI, false, false, false, true>(h, p, grid, st);
+            }
+        }
+        if (p.sib) return launch_scan<256, EPI, false, true>(h, p, grid, st);
+        if (p.nqt == 1) return launch_scan<256, EPI, false, false, true>(h, p, grid, st);   // one query tile: corpus read once -> nt loads
+        return launch_scan<256, EPI, false>(h, p, grid, st);
     } else {
         if (p.nqt == 1) return launch_scan<256, EPI, false, false, true>(h, p, grid, st);
         return launch_scan<256, EPI, false>(h, p, grid, st);

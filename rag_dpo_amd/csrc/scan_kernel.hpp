@@ -217,18 +217,20 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
     };
     // corpus fragments of (tile iteration it, k-step ks): 4 consecutive 1 KiB chunks of this wave's 32-row block
+    int oob_seen = 0;                              // RDX_CHECK_BOUNDS builds only
     const int64_t rb_bytes = (int64_t)KS * 4096;   // bytes of one 32-row block in the scan copy
     const uint32_t lane16 = (uint32_t)lane * 16;
     auto a_src = [&](int it_i, int ks_i) __attribute__((always_inline)) -> const char* {
         const int64_t tile = (int64_t)sched_of(it_i) * p.tile_stride;
 #ifdef RDX_CHECK_BOUNDS
         // test build: every corpus fragment address (prefetches of steps that do not exist included) must lie inside the
-        // scan copy; an address outside is reported and replaced, so the run ends with an error instead of a GPU fault
+        // scan copy; an address outside is remembered (reported once, when the workgroup ends) and replaced, so the run ends
+        // with an error code instead of a GPU fault. Branch-free: the address stays wave-uniform scalar arithmetic.
         {
             const int64_t off = (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096;
             const bool bad = off < 0 || off + 4096 > p.shadow_bytes;
-            if (bad && lane == 0) atomicOr(p.oob, 1);
-            return uniform_ptr(reinterpret_cast<const char*>(p.shadow) + (bad ? 0 : off));
+            oob_seen |= bad ? 1 : 0;
+            return reinterpret_cast<const char*>(p.shadow) + (bad ? (int64_t)0 : off);
         }
 #endif
         return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096;   // wave-uniform
@@ -611,6 +613,9 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     }
 
     if (p.wgt && threadIdx.x == 0) p.wgt[2 * blockIdx.x + 1] = wall_clock64();
+#ifdef RDX_CHECK_BOUNDS
+    if (oob_seen && lane == 0) atomicOr(p.oob, 1);
+#endif
     if constexpr (EPI == EPI_SETMAX) {
         // set id = (stream*8 + wave)*4 + (lane >> 4) ; layout setmax[query][set]
 #pragma unroll
