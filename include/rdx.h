@@ -99,7 +99,13 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * the same corpus tiles for different query tiles (less fabric traffic for ~2-3 % of the throughput while the
  * launch is MFMA-bound; speed and traffic only, never results); "xcd_balance" 0/1 (default 1): the main scan's
  * tiles are split between the 8 XCDs by their measured speed in the previous searches instead of evenly (the XCDs of
- * one chip differ by up to 10 %; speed only); "fuse_epilogue" 0/1 (default 0): B > 128 main scan variant whose per-tile emit check rides inside the
+ * one chip differ by up to 10 %; speed only); "compact_master" 0/1 (default 0; only while the index is empty): the exact copy of the rows keeps the raw bf16 rows as
+ * delivered by rdx_index_add_bf16 plus one fp64 divisor per row (2 B/element + 8 B/row) instead of the normalised fp32 rows
+ * (4 B/element); every normalised element is recomputed as (float)((double)x / den) where the exact re-score, the exact scan
+ * and rdx_index_get need it — the operands and the operation of the ingest normalisation, hence the same bits. With the fp16
+ * scan copy that is 4 instead of 6 B/element for a bf16 corpus (BASELINE config 5). Such an index takes rows through
+ * rdx_index_add_bf16 only (rdx_index_add / _add_stored / _update return RDX_ERR_STATE);
+ * "fuse_epilogue" 0/1 (default 0): B > 128 main scan variant whose per-tile emit check rides inside the
  * first k-step of the next tile instead of interrupting the MFMA stream (speed only; measured equal to 1 % slower);
  * "retry" 0/1 (default 1): queries whose candidate
  * segments overflow get a second MFMA pass as a small batch (denser threshold sample) before the exact full scan. */

@@ -5,6 +5,40 @@
 
 namespace rdx {
 
+// The exact copy of the corpus rows ("master"): what the exact re-score K4, the exact scan K5 and get() read.
+//   default : fp32 [cap][dim], the L2-normalised rows (4 B/element)
+//   compact : the raw bf16 rows as delivered (2 B/element) + each row's divisor den = max(|x|_2, 1e-12) as a double. The
+//             normalised element y_i = (float)((double)x_i / den) is RECOMPUTED wherever it is needed — the same two
+//             operands and the same operation K1 uses, hence the same bits (oracle/rdx_oracle.c) — instead of being stored:
+//             a bf16 corpus (BASELINE config 5) then costs 2 (raw) + 2 (fp16 scan copy) B/element instead of 4 + 2.
+struct MasterView {
+    float* f32;
+    uint16_t* raw16;
+    double* den;
+};
+struct MasterRow {
+    const float4* p32;
+    const ushort4* p16;
+    double den;
+    __device__ __forceinline__ float4 operator[](int g) const {
+        if (p32) return p32[g];
+        const ushort4 u = p16[g];
+        float4 y;
+        y.x = (float)((double)__uint_as_float((uint32_t)u.x << 16) / den);
+        y.y = (float)((double)__uint_as_float((uint32_t)u.y << 16) / den);
+        y.z = (float)((double)__uint_as_float((uint32_t)u.z << 16) / den);
+        y.w = (float)((double)__uint_as_float((uint32_t)u.w << 16) / den);
+        return y;
+    }
+};
+__device__ __forceinline__ MasterRow master_row(const MasterView& mv, int64_t r, int dim) {
+    MasterRow m;
+    m.p32 = mv.f32 ? reinterpret_cast<const float4*>(mv.f32 + r * (int64_t)dim) : nullptr;
+    m.p16 = mv.f32 ? nullptr : reinterpret_cast<const ushort4*>(mv.raw16 + r * (int64_t)dim);
+    m.den = mv.f32 ? 1.0 : mv.den[r];
+    return m;
+}
+
 // write the 4 consecutive elements k..k+3 of a normalised row into a scan copy (corpus: fragment order, queries: LDS images)
 template <bool QUERY>
 __device__ __forceinline__ void shadow_store4(_Float16* __restrict__ shadow, int64_t row, int k, int ksteps,
@@ -24,7 +58,7 @@ __device__ __forceinline__ void shadow_store4(_Float16* __restrict__ shadow, int
 template <bool QUERY>
 __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in, const uint16_t* __restrict__ in_bf16,
                                                    int64_t n, int dim, const int64_t* __restrict__ dst_rows,
-                                                   int64_t row0, float* __restrict__ master,
+                                                   int64_t row0, MasterView master,
                                                    _Float16* __restrict__ shadow, int ksteps, float scale,
                                                    int* __restrict__ bad, int64_t n_pad = 0, int verbatim = 0) {
     const int lane = threadIdx.x & 63;
@@ -68,6 +102,7 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
     if (den < 1e-12) den = 1e-12;
     if (verbatim) den = 1.0;   // rows that ARE stored values (snapshot reload): x / 1.0 == x, kept bit for bit
     const int64_t dst = dst_rows ? dst_rows[i] : row0 + i;
+    if (master.raw16 && lane == 0) master.den[dst] = den;   // compact master: the raw row + its divisor
     for (int g = lane; g < n4; g += 64) {
         const float4 v = load4(g);
         float4 y;
@@ -75,7 +110,8 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
         y.y = (float)((double)v.y / den);
         y.z = (float)((double)v.z / den);
         y.w = (float)((double)v.w / den);
-        if (master) reinterpret_cast<float4*>(master + dst * (int64_t)dim)[g] = y;
+        if (master.f32) reinterpret_cast<float4*>(master.f32 + dst * (int64_t)dim)[g] = y;
+        if (master.raw16) reinterpret_cast<ushort4*>(master.raw16 + dst * (int64_t)dim)[g] = reinterpret_cast<const ushort4*>(in_bf16 + i * (int64_t)dim)[g];
         if (shadow) shadow_store4<QUERY>(shadow, dst, 4 * g, ksteps, scale, y);
     }
 }
@@ -87,31 +123,44 @@ __global__ __launch_bounds__(256) void k_iota64(int64_t* __restrict__ out, int64
 }
 
 // rebuild the scan copy of rows [row0, row0+n) from the (already normalised) master copy
-__global__ __launch_bounds__(256) void k_reshadow(const float* __restrict__ master, int64_t row0, int64_t n, int dim,
+__global__ __launch_bounds__(256) void k_reshadow(MasterView master, int64_t row0, int64_t n, int dim,
                                                   _Float16* __restrict__ shadow, int ksteps, float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const int64_t r = row0 + i;
     const int n4 = dim >> 2;
-    for (int g = lane; g < n4; g += 64)
-        shadow_store4<false>(shadow, r, 4 * g, ksteps, scale, reinterpret_cast<const float4*>(master + r * (int64_t)dim)[g]);
+    const MasterRow row = master_row(master, r, dim);
+    for (int g = lane; g < n4; g += 64) shadow_store4<false>(shadow, r, 4 * g, ksteps, scale, row[g]);
 }
 
 // out[i] = master[rows[i]]  (collection.get(include=["embeddings"]), compaction)
-__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ master, const int64_t* __restrict__ rows,
+__global__ __launch_bounds__(256) void k_gather_rows(MasterView master, const int64_t* __restrict__ rows,
                                                      int64_t n, int dim, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
-    const float4* src = reinterpret_cast<const float4*>(master + rows[i] * (int64_t)dim);
+    const MasterRow src = master_row(master, rows[i], dim);
     float4* dst = reinterpret_cast<float4*>(out + i * (int64_t)dim);
     for (int g = lane; g < (dim >> 2); g += 64) dst[g] = src[g];
 }
 
+// compaction of a compact master: raw rows and divisors move as they are
+__global__ __launch_bounds__(256) void k_gather_raw(MasterView master, const int64_t* __restrict__ rows, int64_t n, int dim,
+                                                    MasterView out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t r = rows[i];
+    const ushort4* src = reinterpret_cast<const ushort4*>(master.raw16 + r * (int64_t)dim);
+    ushort4* dst = reinterpret_cast<ushort4*>(out.raw16 + i * (int64_t)dim);
+    for (int g = lane; g < (dim >> 2); g += 64) dst[g] = src[g];
+    if (lane == 0) out.den[i] = master.den[r];
+}
+
 // exact score of one normalised query (float4 view, global or LDS) against one master row, all 64 lanes get it
 template <class Q4>
-__device__ __forceinline__ float exact_score(const float4* __restrict__ row4, Q4 q4, int n4, int lane) {
+__device__ __forceinline__ float exact_score(const MasterRow& row4, Q4 q4, int n4, int lane) {
     double acc = 0.0;
     for (int g = lane; g < n4; g += 64) {
         const float4 c = row4[g];
@@ -127,7 +176,7 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ row4, Q4
 // K5a. Exact scores of up to QX queries against EVERY row (small problems, huge k, overflow fallback):
 // out[j][r] = score(q_list[j], r), or -inf when the row fails the `where` pre-filter.
 constexpr int QX = 4;
-__global__ __launch_bounds__(256) void k_exact_scores(const float* __restrict__ master, int64_t rows, int dim,
+__global__ __launch_bounds__(256) void k_exact_scores(MasterView master, int64_t rows, int dim,
                                                       const float* __restrict__ qhat, const int32_t* __restrict__ q_list,
                                                       int nq, const uint32_t* __restrict__ allow,
                                                       float* __restrict__ out) {
@@ -147,7 +196,7 @@ __global__ __launch_bounds__(256) void k_exact_scores(const float* __restrict__ 
     // at the reference's 16,919 rows). Per lane the groups are still added in increasing g: the oracle's lane order.
     for (int64_t r = wave0; r < rows; r += nwaves) {
         const bool ok = !allow || ((allow[r >> 5] >> (r & 31)) & 1u);
-        const float4* row4 = reinterpret_cast<const float4*>(master + r * (int64_t)dim);
+        const MasterRow row4 = master_row(master, r, dim);
         double acc[QX];
 #pragma unroll
         for (int j = 0; j < QX; ++j) acc[j] = 0.0;

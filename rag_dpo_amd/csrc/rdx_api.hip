@@ -91,7 +91,11 @@ struct rdx_index {
     int dim = 0, dim_pad = 0, ksteps = 0, scale_log2 = 0;
     int n_cu = 256;
     int64_t rows = 0, cap = 0;   // cap is a multiple of 256
-    float* master = nullptr;     // [cap][dim]
+    float* master = nullptr;     // [cap][dim] normalised fp32 rows (default), or NULL with option compact_master:
+    uint16_t* raw16 = nullptr;   //   [cap][dim] raw bf16 rows as delivered ...
+    double* den = nullptr;       //   [cap] ... and their divisors max(|x|, 1e-12); k_rows.hpp MasterView
+    int compact = 0;             // option "compact_master" (settable while the index is empty): 4 instead of 6 B/element
+    MasterView mv() const { return MasterView{master, raw16, den}; }
     _Float16* shadow = nullptr;  // [cap][dim_pad] fp16 scan copy in MFMA fragment order (rdx_common.hpp corpus_off)
     hipStream_t own_stream = nullptr;
     std::mutex mu;
@@ -141,23 +145,46 @@ static int set_device(const rdx_index* h) {
     return RDX_OK;
 }
 
+static void free_master(float* m, uint16_t* r, double* d) {
+    if (m) (void)hipFree(m);
+    if (r) (void)hipFree(r);
+    if (d) (void)hipFree(d);
+}
+
+// master storage for `cap` rows in the index's mode
+static hipError_t alloc_master(const rdx_index* h, int64_t cap, float** m, uint16_t** r, double** d) {
+    *m = nullptr;
+    *r = nullptr;
+    *d = nullptr;
+    if (!h->compact) return hipMalloc((void**)m, (size_t)cap * h->dim * 4);
+    hipError_t e = hipMalloc((void**)r, (size_t)cap * h->dim * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)d, (size_t)cap * 8);
+    if (e != hipSuccess) {
+        free_master(nullptr, *r, *d);
+        *r = nullptr;
+        *d = nullptr;
+    }
+    return e;
+}
+
 static int grow(rdx_index* h, int64_t need_rows) {
     if (need_rows <= h->cap) return RDX_OK;
     int64_t ncap = std::max<int64_t>(need_rows, h->cap + h->cap / 2);
     ncap = (ncap + 255) / 256 * 256;
     float* nm = nullptr;
+    uint16_t* nr16 = nullptr;
+    double* nd = nullptr;
     _Float16* ns = nullptr;
-    hipError_t e = hipMalloc((void**)&nm, (size_t)ncap * h->dim * 4);
+    hipError_t e = alloc_master(h, ncap, &nm, &nr16, &nd);
     if (e == hipSuccess) e = hipMalloc((void**)&ns, shadow_bytes(h, ncap));
     if (e != hipSuccess && ncap > (need_rows + 255) / 256 * 256) {   // retry without head-room
-        if (nm) (void)hipFree(nm);
-        nm = nullptr;
+        free_master(nm, nr16, nd);
         ncap = (need_rows + 255) / 256 * 256;
-        e = hipMalloc((void**)&nm, (size_t)ncap * h->dim * 4);
+        e = alloc_master(h, ncap, &nm, &nr16, &nd);
         if (e == hipSuccess) e = hipMalloc((void**)&ns, shadow_bytes(h, ncap));
     }
     if (e != hipSuccess) {
-        if (nm) (void)hipFree(nm);
+        free_master(nm, nr16, nd);
         return fail(RDX_ERR_NOMEM, std::string("growing index to ") + std::to_string(ncap) + " rows: " + hipGetErrorString(e));
     }
     hipStream_t st = h->own_stream;
@@ -165,7 +192,7 @@ static int grow(rdx_index* h, int64_t need_rows) {
     if (h->row_map) {   // the id map grows with the rows: old entries kept, new ones start as local + row_base
         e = hipMalloc((void**)&nr, (size_t)ncap * 8);
         if (e != hipSuccess) {
-            (void)hipFree(nm);
+            free_master(nm, nr16, nd);
             (void)hipFree(ns);
             return fail(RDX_ERR_NOMEM, std::string("growing the row id map: ") + hipGetErrorString(e));
         }
@@ -174,14 +201,21 @@ static int grow(rdx_index* h, int64_t need_rows) {
     }
     HIP_TRY(hipMemsetAsync(ns, 0, shadow_bytes(h, ncap), st));
     if (h->rows > 0) {
-        HIP_TRY(hipMemcpyAsync(nm, h->master, (size_t)h->rows * h->dim * 4, hipMemcpyDeviceToDevice, st));
+        if (h->compact) {
+            HIP_TRY(hipMemcpyAsync(nr16, h->raw16, (size_t)h->rows * h->dim * 2, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(nd, h->den, (size_t)h->rows * 8, hipMemcpyDeviceToDevice, st));
+        } else {
+            HIP_TRY(hipMemcpyAsync(nm, h->master, (size_t)h->rows * h->dim * 4, hipMemcpyDeviceToDevice, st));
+        }
         HIP_TRY(hipMemcpyAsync(ns, h->shadow, shadow_bytes(h, h->cap), hipMemcpyDeviceToDevice, st));
     }
     HIP_TRY(hipStreamSynchronize(st));
-    if (h->master) (void)hipFree(h->master);
+    free_master(h->master, h->raw16, h->den);
     if (h->shadow) (void)hipFree(h->shadow);
     if (h->row_map) (void)hipFree(h->row_map);
     h->master = nm;
+    h->raw16 = nr16;
+    h->den = nd;
     h->shadow = ns;
     h->row_map = nr;
     h->cap = ncap;
@@ -239,7 +273,7 @@ extern "C" int rdx_index_destroy(rdx_index* h) {
     if (!h) return RDX_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->own_stream);
-    if (h->master) (void)hipFree(h->master);
+    free_master(h->master, h->raw16, h->den);
     if (h->shadow) (void)hipFree(h->shadow);
     if (h->row_map) (void)hipFree(h->row_map);
     for (DevBuf* b : {&h->staging, &h->qraw, &h->qhat, &h->qshadow, &h->tau, &h->cntw, &h->cand, &h->setmax, &h->exact_list,
@@ -283,6 +317,10 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "sib_sync") h->sib_sync = value != 0;
     else if (n == "retry") h->retry = value != 0;
     else if (n == "fuse_epilogue") h->fuse_epilogue = value != 0;
+    else if (n == "compact_master") {
+        if (h->rows > 0 || h->cap > 0) return fail(RDX_ERR_STATE, "compact_master can only be chosen while the index is empty");
+        h->compact = value != 0;
+    }
     else if (n == "xcd_balance") {
         h->xcd_balance = value != 0;
         for (double& w : h->xw) w = 1.0;
@@ -328,7 +366,7 @@ static int ingest(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int s
         const int grid = (int)((m + 3) / 4);
         hipLaunchKernelGGL(k_normalize<false>, dim3(grid), dim3(256), 0, st, is_bf16 ? nullptr : (const float*)src,
                            is_bf16 ? (const uint16_t*)src : nullptr, m, h->dim, d_dst_ids ? d_dst_ids + off : nullptr,
-                           row0 + off, h->master, h->shadow, h->ksteps, h->scale(), h->bad.as<int>(), (int64_t)0, verbatim ? 1 : 0);
+                           row0 + off, h->mv(), h->shadow, h->ksteps, h->scale(), h->bad.as<int>(), (int64_t)0, verbatim ? 1 : 0);
         HIP_TRY(hipGetLastError());
         if (space == RDX_HOST) HIP_TRY(hipStreamSynchronize(st));   // staging is reused by the next chunk
     }
@@ -344,6 +382,8 @@ static int add_impl(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (n == 0) return RDX_OK;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->compact && (!is_bf16 || verbatim))
+        return fail(RDX_ERR_STATE, "this index keeps a compact master (raw bf16 rows + divisors): rows must arrive through rdx_index_add_bf16");
     RDX_TRY(set_device(h));
     RDX_TRY(grow(h, h->rows + n));
     RDX_TRY(ingest(h, rows, is_bf16, n, space, h->rows, nullptr, verbatim));
@@ -389,6 +429,7 @@ extern "C" int rdx_index_update(rdx_index* h, const int64_t* row_ids, const floa
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (n == 0) return RDX_OK;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (h->compact) return fail(RDX_ERR_STATE, "rdx_index_update takes fp32 rows: not available on an index with a compact (bf16) master");
     RDX_TRY(set_device(h));
     const int64_t* d_ids = nullptr;
     RDX_TRY(stage_ids(h, row_ids, n, space, &d_ids));
@@ -411,7 +452,7 @@ extern "C" int rdx_index_get(rdx_index* h, const int64_t* row_ids, int64_t n, fl
             RDX_TRY(h->staging.ensure((size_t)STAGE_ROWS * h->dim * 4));
             dst = h->staging.as<float>();
         }
-        hipLaunchKernelGGL(k_gather_rows, dim3((int)((m + 3) / 4)), dim3(256), 0, st, h->master, d_ids + off, m, h->dim, dst);
+        hipLaunchKernelGGL(k_gather_rows, dim3((int)((m + 3) / 4)), dim3(256), 0, st, h->mv(), d_ids + off, m, h->dim, dst);
         HIP_TRY(hipGetLastError());
         if (space == RDX_HOST) {
             HIP_TRY(hipMemcpyAsync(out + (size_t)off * h->dim, dst, (size_t)m * h->dim * 4, hipMemcpyDeviceToHost, st));
@@ -433,29 +474,36 @@ extern "C" int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_ke
     hipStream_t st = h->own_stream;
     const int64_t ncap = std::max<int64_t>(256, (n_keep + 255) / 256 * 256);
     float* nm = nullptr;
+    uint16_t* nr16 = nullptr;
+    double* nd = nullptr;
     _Float16* ns = nullptr;
-    HIP_TRY(hipMalloc((void**)&nm, (size_t)ncap * h->dim * 4));
-    hipError_t e = hipMalloc((void**)&ns, shadow_bytes(h, ncap));
+    hipError_t e = alloc_master(h, ncap, &nm, &nr16, &nd);
+    if (e == hipSuccess) e = hipMalloc((void**)&ns, shadow_bytes(h, ncap));
     if (e != hipSuccess) {
-        (void)hipFree(nm);
+        free_master(nm, nr16, nd);
         return fail(RDX_ERR_NOMEM, std::string("compact: ") + hipGetErrorString(e));
     }
     HIP_TRY(hipMemsetAsync(ns, 0, shadow_bytes(h, ncap), st));
     if (n_keep > 0) {
         RDX_TRY(h->ids.ensure((size_t)n_keep * 8));
         HIP_TRY(hipMemcpyAsync(h->ids.p, keep, (size_t)n_keep * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_gather_rows, dim3((int)((n_keep + 3) / 4)), dim3(256), 0, st, h->master, h->ids.as<int64_t>(), n_keep,
-                           h->dim, nm);
-        hipLaunchKernelGGL(k_reshadow, dim3((int)((n_keep + 3) / 4)), dim3(256), 0, st, nm, (int64_t)0, n_keep, h->dim, ns,
+        const MasterView nv{nm, nr16, nd};
+        if (h->compact)
+            hipLaunchKernelGGL(k_gather_raw, dim3((int)((n_keep + 3) / 4)), dim3(256), 0, st, h->mv(), h->ids.as<int64_t>(), n_keep, h->dim, nv);
+        else
+            hipLaunchKernelGGL(k_gather_rows, dim3((int)((n_keep + 3) / 4)), dim3(256), 0, st, h->mv(), h->ids.as<int64_t>(), n_keep, h->dim, nm);
+        hipLaunchKernelGGL(k_reshadow, dim3((int)((n_keep + 3) / 4)), dim3(256), 0, st, nv, (int64_t)0, n_keep, h->dim, ns,
                            h->ksteps, h->scale());
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(st));
-    if (h->master) (void)hipFree(h->master);
+    free_master(h->master, h->raw16, h->den);
     if (h->shadow) (void)hipFree(h->shadow);
     if (h->row_map) (void)hipFree(h->row_map);   // rows were renumbered: the caller sets a new id map (or none)
     h->row_map = nullptr;
     h->master = nm;
+    h->raw16 = nr16;
+    h->den = nd;
     h->shadow = ns;
     h->cap = ncap;
     h->rows = n_keep;
@@ -516,7 +564,7 @@ extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim,
     }
     HIP_TRY(hipMemsetAsync(sc.bad.p, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_normalize<false>, dim3((int)((n + 3) / 4)), dim3(256), 0, st, d_in, (const uint16_t*)nullptr, n, dim,
-                       (const int64_t*)nullptr, (int64_t)0, d_out, (_Float16*)nullptr, 0, 1.0f, sc.bad.as<int>());
+                       (const int64_t*)nullptr, (int64_t)0, MasterView{d_out, nullptr, nullptr}, (_Float16*)nullptr, 0, 1.0f, sc.bad.as<int>());
     HIP_TRY(hipGetLastError());
     int b = 0;
     if (space == RDX_HOST) HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)n * dim * 4, hipMemcpyDeviceToHost, st));
@@ -589,7 +637,7 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
     for (int j0 = 0; j0 < n_list; j0 += QX) {
         const int nq = std::min(QX, n_list - j0);
         if (h->rows > 0) {
-            hipLaunchKernelGGL(k_exact_scores, dim3(std::max(grid_rows, 1)), dim3(256), (size_t)nq * h->dim * 4, st, h->master,
+            hipLaunchKernelGGL(k_exact_scores, dim3(std::max(grid_rows, 1)), dim3(256), (size_t)nq * h->dim * 4, st, h->mv(),
                                h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>());
             HIP_TRY(hipGetLastError());
         }
@@ -688,7 +736,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     const unsigned long long seq = ++h->seq;
     mark(0);
     hipLaunchKernelGGL(k_normalize<true>, dim3((int)((nq_pad + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
-                       (const int64_t*)nullptr, (int64_t)0, h->qhat.as<float>(), h->qshadow.as<_Float16>(), h->ksteps, h->scale(),
+                       (const int64_t*)nullptr, (int64_t)0, MasterView{h->qhat.as<float>(), nullptr, nullptr}, h->qshadow.as<_Float16>(), h->ksteps, h->scale(),
                        d_bad, (int64_t)nq_pad);
     HIP_TRY(hipGetLastError());
     mark(1);
@@ -814,7 +862,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             const size_t lds = (size_t)list_cap * 8;
             RDX_TRY(ensure_dynamic_lds(h, (const void*)k_refine, lds));
             hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(k > 32 ? 1024 : 256), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
-                               list_cap, k, h->two_e(), h->qhat.as<float>(), h->master, h->dim, h->row_base, h->row_map, d_score, d_row, d_count,
+                               list_cap, k, h->two_e(), h->qhat.as<float>(), h->mv(), h->dim, h->row_base, h->row_map, d_score, d_row, d_count,
                                h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
             HIP_TRY(hipGetLastError());
         }

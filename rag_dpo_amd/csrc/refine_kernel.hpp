@@ -68,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
 //   A segment, list or P overflow cannot be answered here: the query is flagged for the exact full scan.
 __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
                                                 int n_streams, uint32_t capw, uint32_t list_cap, int k, float two_e,
-                                                const float* __restrict__ qhat, const float* __restrict__ master, int dim,
+                                                const float* __restrict__ qhat, MasterView master, int dim,
                                                 int64_t row_base, const int64_t* __restrict__ row_map,
                                                 float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                 int32_t* __restrict__ out_count, int32_t* __restrict__ exact_list,
@@ -143,8 +143,7 @@ __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4* q4 = reinterpret_cast<const float4*>(qhat + (int64_t)q * dim);
     for (int i = wave; i < p; i += (int)(blockDim.x >> 6)) {
-        const float4* row4 = reinterpret_cast<const float4*>(master + s_r[i] * (int64_t)dim);
-        const float s = exact_score(row4, q4, dim >> 2, lane);
+        const float s = exact_score(master_row(master, s_r[i], dim), q4, dim >> 2, lane);
         if (lane == 0) s_s[i] = s;
     }
     __syncthreads();

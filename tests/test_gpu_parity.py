@@ -220,6 +220,44 @@ def test_bf16_corpus(eng, oracle):
     _check(oracle, ix, cb.to(torch.float32).numpy(), q, 10, expect_path=0)
 
 
+def test_compact_master_for_bf16_corpora(eng, oracle):
+    """option compact_master (BASELINE config 5: a bf16 corpus at 2 + 2 instead of 4 + 2 B/element): the exact copy holds the raw
+    bf16 rows + one divisor per row and every normalised element is recomputed as (float)((double)x / den) where it is
+    needed. Ids, score bits and the rows get() returns must equal the oracle on the bf16-widened values and the default
+    (fp32 master) index — on the MFMA path, the exact path, through a row bitmap, after growth and after compaction."""
+    import torch
+    rng = np.random.default_rng(3)
+    corpus = synth.make_corpus(30000, 1024)
+    cb = torch.from_numpy(corpus).to(torch.bfloat16)
+    wide = cb.to(torch.float32).numpy()
+    ix, ref = eng.HipIndex(1024), eng.HipIndex(1024)
+    ix.set_option("compact_master", 1)
+    for a in range(0, 30000, 7000):                   # several adds: the raw rows and divisors survive growth
+        ix.add_bf16(cb[a:a + 7000]); ref.add_bf16(cb[a:a + 7000])
+    q = synth.make_queries(70, 1024, corpus)
+    np.testing.assert_array_equal(ix.get(np.arange(0, 30000, 7)), oracle.normalize_rows(wide)[::7])
+    for opt in ("force_fast", "force_exact"):
+        ix.set_option(opt, 1); ref.set_option(opt, 1)
+        _check(oracle, ix, wide, q, 10, expect_path=0 if opt == "force_fast" else 1)
+        allow = rng.random(30000) < 0.3
+        _check(oracle, ix, wide, q[:9], 50, allow)
+        a, b = ix.search(q, 100), ref.search(q, 100)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+        ix.set_option(opt, 0); ref.set_option(opt, 0)
+    keep = np.flatnonzero(rng.random(30000) < 0.5)
+    ix.compact(keep)
+    ix.set_option("force_fast", 1)
+    _check(oracle, ix, wide[keep], q, 10, expect_path=0)
+    with pytest.raises(Exception, match="compact"):
+        ix.add(corpus[:5])                             # fp32 rows cannot enter a compact (bf16) master
+    with pytest.raises(Exception, match="compact"):
+        ix.update(np.array([0]), corpus[:1])
+    with pytest.raises(Exception, match="empty"):
+        ref.set_option("compact_master", 1)            # only while the index is empty
+    ix.close(); ref.close()
+
+
 def test_rejects_nan(eng):
     corpus = synth.make_corpus(100, 1024)
     bad = corpus.copy(); bad[50, 7] = np.nan
