@@ -101,7 +101,7 @@ struct rdx_index {
     std::mutex mu;
 
     // options
-    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 0;
+    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 0, force_bn = 0;
     double xw[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // relative speed of the XCDs as the last main scans showed it (sum 8)
     unsigned long long wg_times[1024] = {};    // start/end stamps of the last main scan's workgroups (host copy)
     int sample_div = 64;
@@ -317,6 +317,10 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "sib_sync") h->sib_sync = value != 0;
     else if (n == "retry") h->retry = value != 0;
     else if (n == "fuse_epilogue") h->fuse_epilogue = value != 0;
+    else if (n == "force_bn") {
+        if (value != 0 && value != 64 && value != 128 && value != 256) return fail(RDX_ERR_INVALID, "force_bn must be 0 (automatic), 64, 128 or 256");
+        h->force_bn = (int)value;
+    }
     else if (n == "compact_master") {
         if (h->rows > 0 || h->cap > 0) return fail(RDX_ERR_STATE, "compact_master can only be chosen while the index is empty");
         h->compact = value != 0;
@@ -601,8 +605,12 @@ static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t 
 
 template <int EPI>
 static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, int grid, hipStream_t st) {
-    if (bn == 64) return res ? launch_scan<64, EPI, true>(h, p, grid, st) : launch_scan<64, EPI, false>(h, p, grid, st);
-    if (bn == 128) return launch_scan<128, EPI, false>(h, p, grid, st);
+    // NTT (5th template argument): one query tile -> every corpus byte is read by exactly one workgroup -> non-temporal loads
+    if (bn == 64) {
+        if (p.nqt == 1) return res ? launch_scan<64, EPI, true, false, true>(h, p, grid, st) : launch_scan<64, EPI, false, false, true>(h, p, grid, st);
+        return res ? launch_scan<64, EPI, true>(h, p, grid, st) : launch_scan<64, EPI, false>(h, p, grid, st);
+    }
+    if (bn == 128) return p.nqt == 1 ? launch_scan<128, EPI, false, false, true>(h, p, grid, st) : launch_scan<128, EPI, false>(h, p, grid, st);
     if constexpr (EPI == EPI_EMIT) {
 #ifdef RDX_CHECK_BOUNDS
         constexpr bool HAVE_FUSED = false;   // the address-checking test build carries one more live value: no fused variants
@@ -761,7 +769,10 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         }
         RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st));
     } else {
-        const int bn = nq <= 64 ? 64 : (nq <= 128 ? 128 : 256);
+        // queries per workgroup: 64 (tile resident in LDS), 128, 256. 257..384 queries run as three 128-query tiles rather than
+        // one full and one half-empty 256-query tile (measured at 1M x 1024, B = 384: 0.78 vs 0.84 ms; tools/bn_sweep.py)
+        int bn = nq <= 64 ? 64 : (nq <= 128 ? 128 : ((nq > 256 && nq <= 384) ? 128 : 256));
+        if (h->force_bn && (nq + h->force_bn - 1) / h->force_bn <= 32) bn = h->force_bn;   // developer option: queries per workgroup
         nqt = (int)((nq + bn - 1) / bn);
         grid = std::max(8, h->n_cu / 8 * 8);
         const int wpx = grid / 8;

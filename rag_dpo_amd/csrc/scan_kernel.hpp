@@ -132,7 +132,7 @@ __device__ __forceinline__ void wait_vmcnt_keep(half8 (&a)[4]) {
 template <int BN, int EPI, bool HAS_MASK, bool RES, bool SIBT = false, bool NTT = false, bool FUSEDT = false>
 __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     constexpr bool FUSED = FUSEDT && EPI == EPI_EMIT;
-    constexpr bool NT_A = RDX_NT_SMALL && (BN <= 128 || NTT);   // host: BN <= 128 launches and NTT launches have ONE query tile
+    constexpr bool NT_A = RDX_NT_SMALL && NTT;   // host: NTT launches have ONE query tile (every corpus byte is read by one workgroup)
     constexpr int B_BYTES = BN * BK * 2;  // one k-step image of this workgroup's queries
     constexpr int NPB = BN / 64;          // 1 KiB DMA pieces per wave per query image
     // Sibling lock-step (speed only). The nqt workgroups of a stream read the same corpus tiles; nothing else keeps them

@@ -12,7 +12,7 @@ f=glob.glob("$OUT/*/*_counter_collection.csv")[0]
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     if 'k_scan' in r['Kernel_Name']:
-        agg[r['Kernel_Name'][:40]][r['Counter_Name']].append(float(r['Counter_Value']))
+        agg[r['Kernel_Name'].split('(')[0][:70]][r['Counter_Name']].append(float(r['Counter_Value']))
         agg[r['Kernel_Name'][:40]]['_dur_ns'].append(float(r['End_Timestamp'])-float(r['Start_Timestamp']))
 for k,v in agg.items():
     print(k, {c: round(sum(x)/len(x),1) for c,x in v.items()})

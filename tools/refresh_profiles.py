@@ -1,9 +1,9 @@
-"""Copy the judged summaries of one measurement run from gpurun_out/ (scratch) into profiles/r01 (tracked).
-usage: python tools/refresh_profiles.py <bench dir under gpurun_out> <prof tag> [round dir]"""
-import collections, csv, glob, json, os, shutil, sys
+"""Copy the judged summaries of one measurement run from gpurun_out/ (scratch) into profiles/<round> (tracked).
+usage: python tools/refresh_profiles.py <bench dir under gpurun_out> <prof tag> <round dir, e.g. r02>"""
+import collections, csv, datetime, glob, json, os, shutil, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-bench_dir, tag = sys.argv[1], sys.argv[2]
-dst = os.path.join(R, "profiles", sys.argv[3] if len(sys.argv) > 3 else "r01")
+bench_dir, tag, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
+dst = os.path.join(R, "profiles", rnd)
 src = os.path.join(R, "gpurun_out", f"prof_{tag}")
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(dst + "/*"):
@@ -29,13 +29,13 @@ for k, v in out.items():
 out["_note"] = ("separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py --steps 5 --warmup 2 --no-cpu`; bytes = "
                 "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads, MI355X_MICROARCH.md HBM section)")
 json.dump(out, open(dst + "/c4_n1_pmc_summary.json", "w"), indent=1)
-main = [v for k, v in out.items() if k.startswith("void rdx::k_scan<256, 1, false, false")][0]["hbm_side_bytes_per_launch"]
-json.dump({"c4_n1": main, "_source": "profiles/r01/c4_n1_pmc_summary.json (main scan k_scan<256,1,false,false>, bytes per launch)"},
+main = [v for k, v in out.items() if k.startswith("void rdx::k_scan<256, 1, false, false, false, false")][0]["hbm_side_bytes_per_launch"]
+json.dump({"c4_n1": {"bytes_per_launch": main,
+                     "source": f"profiles/{rnd}/c4_n1_pmc_summary.json (main scan k_scan<256,1,false,false,...>, rocprofv3 --pmc run of "
+                               f"{datetime.date.today().isoformat()})"}},
           open(R + "/profiles/traffic.json", "w"), indent=1)
 for f in glob.glob(os.path.join(R, "gpurun_out", bench_dir, "*.json")):
     shutil.copy(f, os.path.join(dst, os.path.basename(f).replace(".json", "_n1_bench.json")))
-for extra, name in ((f"pmc_{tag}.log", "sq_grbm_2Mrows_pmc.txt"), (f"pmc_{tag}_sib.log", "c4_n1_sib_sync_fetch_pmc.txt")):
-    p = os.path.join(R, "gpurun_out", extra)
-    if os.path.exists(p):
-        shutil.copy(p, os.path.join(dst, name))
+for extra in glob.glob(os.path.join(R, "gpurun_out", bench_dir, "*.txt")) + glob.glob(os.path.join(R, "gpurun_out", bench_dir, "*_kernel_stats.csv")):
+    shutil.copy(extra, os.path.join(dst, os.path.basename(extra)))
 print("traffic", main, sorted(os.listdir(dst)))
