@@ -275,6 +275,7 @@ def main():
     barrier()
     enc_ev.clear()
     scan_ms, tot_ms, stats = 0.0, 0.0, None
+    exact_ms = 0.0
     serial = None
     if encode and not args.no_overlap:
         # C5 step = encode B texts + search. The two are pipelined: a worker thread runs the search of batch i on its own
@@ -319,6 +320,7 @@ def main():
                 q_next, ready = encode_on_stream()
             _, st = fut.result()
             scan_ms += st["ms_scan_main"]
+            exact_ms += st["ms_exact"]
             tot_ms += st["ms_total"]
             stats = st
         barrier()
@@ -330,6 +332,7 @@ def main():
             step()
             st = shard.index.last_stats()   # host struct copy, no device work
             scan_ms += st["ms_scan_main"]
+            exact_ms += st["ms_exact"]
             tot_ms += st["ms_total"]
             stats = st
         barrier()
@@ -401,6 +404,18 @@ def main():
                          "traffic_is": "fabric bytes per launch of this kernel from an EARLIER rocprofv3 --pmc run "
                                        "(2*FETCH_SIZE + WRITE_SIZE, separate passes), not measured in this run",
                          "traffic_source": traffic_src})
+        if stats and stats["path"] == 1 and exact_ms > 0:
+            # small corpora are answered by the exact full scan alone (K5a k_exact_scores + K5b k_select_dense): one fp32 read
+            # of the corpus per <= 4 queries, HBM/latency-bound
+            sec = exact_ms / args.steps * 1e-3
+            by = -(-B // 4) * n_local * dim * 4.0 + B * n_local * 4.0 * 2
+            roof = {"bound": "hbm", "achieved": round(by / sec / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(by / sec / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                    "kernel": "rdx::k_exact_scores + rdx::k_select_dense (exact path of small corpora)",
+                    "avg_launch_ms": round(exact_ms / args.steps, 4), "timer": "HIP events recorded by librdx around the two kernels",
+                    "bytes_read_per_launch": by,
+                    "bytes_read_is": "ceil(B/4) fp32 passes over the corpus + the dense score rows written and read back",
+                    "launch_rows": n_local, "launch_queries": B}
         # the same corpus swept with a small batch: the HBM-bound regime of the same kernel (BASELINE.json's
         # ">= 50 % of the HBM roofline on the 10M x 1024 scan" is about THIS regime; at B = 1024 the scan is MFMA-bound)
         small = None

@@ -758,7 +758,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     int grid = 0, G = 0, nqt = 0;
     bool balance = false;
     if (exact_only) {
-        for (int i = 2; i <= 5; ++i) mark(i);
+        for (int i = 2; i <= 3; ++i) mark(i);   // events 3..4 bracket the dominant kernels of this path too (K5a + K5b)
         if ((size_t)nq_pad * 4 > h->iota.bytes) {   // identity query list, uploaded once (grow-only), not per search
             RDX_TRY(h->iota.ensure((size_t)nq_pad * 4));
             const size_t cnt = h->iota.bytes / 4;
@@ -768,6 +768,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             HIP_TRY(hipStreamSynchronize(st));
         }
         RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st));
+        for (int i = 4; i <= 5; ++i) mark(i);
     } else {
         // queries per workgroup: 64 (tile resident in LDS), 128, 256. 257..384 queries run as three 128-query tiles rather than
         // one full and one half-empty 256-query tile (measured at 1M x 1024, B = 384: 0.78 vs 0.84 ms; tools/bn_sweep.py)
@@ -990,11 +991,12 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         float tot = 0;
         (void)hipEventElapsedTime(&tot, h->ev[0], h->ev[6]);
         acc_stats->ms_total += tot;
-    } else if (prof_main && !exact_only) {
+    } else if (prof_main) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, h->ev[3], h->ev[4]);   // both completed: the mailbox came after them in the stream
         acc_stats->profiled = 2;
-        acc_stats->ms_scan_main += ms;
+        if (exact_only) acc_stats->ms_exact += ms;   // exact path: K5a + K5b
+        else acc_stats->ms_scan_main += ms;
     }
     return RDX_OK;
 }
