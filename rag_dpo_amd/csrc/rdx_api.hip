@@ -873,7 +873,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             while (list_cap < (uint32_t)REFINE_LIST && list_cap < 16.0 * exp_hits * n_streams) list_cap *= 2;
             const size_t lds = (size_t)list_cap * 8;
             RDX_TRY(ensure_dynamic_lds(h, (const void*)k_refine, lds));
-            hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(k > 32 ? 1024 : 256), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
+            hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(1024), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
                                list_cap, k, h->two_e(), h->qhat.as<float>(), h->mv(), h->dim, h->row_base, h->row_map, d_score, d_row, d_count,
                                h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>());
             HIP_TRY(hipGetLastError());

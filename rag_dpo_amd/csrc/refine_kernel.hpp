@@ -86,20 +86,29 @@ __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand,
     int64_t* o_r = out_row + (int64_t)q * k;
     if (threadIdx.x == 0) overflow = 0;
     __syncthreads();
-    // segment sizes -> exclusive prefix (n_streams <= 512: two per thread, serial scan by one wave is plenty)
+    // segment sizes -> exclusive prefix. Wave 0 scans them 64 at a time with shuffles (n_streams <= 512: at most 8 rounds; the
+    // serial loop this replaces was 3-5 us of the kernel at 256 streams)
     for (int w = threadIdx.x; w < n_streams; w += blockDim.x) {
         const uint32_t c = cntw[(int64_t)q * n_streams + w];
         if (c > capw) overflow = 1;
         seg_off[w + 1] = c > capw ? capw : c;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        seg_off[0] = 0;
-        for (int w = 0; w < n_streams; ++w) {
-            acc += seg_off[w + 1];
-            seg_off[w + 1] = acc;
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        uint32_t carry = 0;
+        for (int base = 0; base < n_streams; base += 64) {
+            const int w = base + l;
+            uint32_t v = w < n_streams ? seg_off[w + 1] : 0u;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(v, off, 64);
+                if (l >= off) v += t;
+            }
+            if (w < n_streams) seg_off[w + 1] = carry + v;      // inclusive prefix -> offset of segment w + 1
+            carry += __shfl(v, 63, 64);
         }
+        if (l == 0) seg_off[0] = 0;
     }
     __syncthreads();
     const uint32_t m = seg_off[n_streams];

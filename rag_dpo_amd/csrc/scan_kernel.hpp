@@ -334,42 +334,43 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     if (total > 0) {
-        half8 a0[4], a1[4];   // corpus fragments of the even / odd k-steps in flight
-        // ---- prologue: query images of steps 0..2 (ring) or the whole tile (resident), corpus fragments of steps 0 and 1 ----
+        // Corpus fragments in flight: AD register sets, step s uses set s % AD and refills it with step s + AD. Two sets
+        // (two k-steps of prefetch) are all the 256-query kernels have registers for; the resident 64-query kernel (no DMA,
+        // no barrier, 140 VGPRs) takes four: its launches are HBM-latency-bound — tiny corpora run ONE or two tiles per
+        // workgroup, 16 dependent k-steps each (100 k x 1024, B = 64: main scan 42 -> 2x us, bootstrap 19 -> 1x us).
+        constexpr int AD = (RES && BN == 64) ? 4 : 2;
+        half8 a0[4], a1[4], a2[4], a3[4];   // (a2, a3 unused and eliminated when AD == 2)
+        // ---- prologue: query images of steps 0..2 (ring) or the whole tile (resident), corpus fragments of steps 0..AD-1 ----
         if constexpr (RES) {
             for (int ks_i = 0; ks_i < KS; ++ks_i) issue_b(ks_i, ks_i);
         } else {
 #pragma unroll
             for (int j = 0; j < 3; ++j) issue_b(j % KS, j);   // step j reads k-step image j mod KS (one query tile for all corpus tiles)
         }
-        {
-            const char* s0 = a_src(0, 0);
-            gload16<NT_A, 0>(a0[0], s0, lane16);
-            gload16<NT_A, 1024>(a0[1], s0, lane16);
-            gload16<NT_A, 2048>(a0[2], s0, lane16);
-            gload16<NT_A, 3072>(a0[3], s0, lane16);
-        }
-        int it1 = 0, ks1 = 1;
-        if (ks1 == KS) { ks1 = 0; it1 = 1; }
         // Every step issues its V loads unconditionally (steps that do not exist re-read the stream's first step: valid
         // memory, never consumed) so that the counted waits stay uniform and no conditional copy of an in-flight
         // register is ever needed. An asm load must not be in flight towards a register the compiler considers dead
-        // (it would reuse the register and the late write-back would corrupt it): both fragment sets are kept alive
+        // (it would reuse the register and the late write-back would corrupt it): all fragment sets are kept alive
         // until the final s_waitcnt vmcnt(0) below.
-        const bool have1 = total > 1;
-        {
-            const char* s1 = a_src(have1 ? it1 : 0, have1 ? ks1 : 0);
-            gload16<NT_A, 0>(a1[0], s1, lane16);
-            gload16<NT_A, 1024>(a1[1], s1, lane16);
-            gload16<NT_A, 2048>(a1[2], s1, lane16);
-            gload16<NT_A, 3072>(a1[3], s1, lane16);
+        auto first_load = [&](half8 (&af)[4], int j) __attribute__((always_inline)) {   // fragments of step j (or of step 0 when j does not exist)
+            const bool have = j < total;
+            const char* sj = a_src(have ? j / KS : 0, have ? j % KS : 0);
+            gload16<NT_A, 0>(af[0], sj, lane16);
+            gload16<NT_A, 1024>(af[1], sj, lane16);
+            gload16<NT_A, 2048>(af[2], sj, lane16);
+            gload16<NT_A, 3072>(af[3], sj, lane16);
+        };
+        first_load(a0, 0);
+        first_load(a1, 1);
+        if constexpr (AD == 4) {
+            first_load(a2, 2);
+            first_load(a3, 3);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // the only barrier that waits for memory: every wave's prologue DMA has landed
 
-        int it = 0, ks = 0;            // step being computed
-        int it2 = it1, ks2 = ks1 + 1;  // step s+2 (corpus fragments prefetched during step s)
-        if (ks2 >= KS) { ks2 -= KS; ++it2; }
+        int it = 0, ks = 0;                  // step being computed
+        int it2 = AD / KS, ks2 = AD % KS;    // step s+AD (corpus fragments prefetched during step s)
         int slot_c = 0;                // ring slot of step s (= s mod 4)
         int ksb = 3 % KS;              // k-step image that step s+3 reads (issued during step s)
 
@@ -402,9 +403,9 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         // MFMA stream together once per tile for ~290 vector instructions; ablation: 7 % of the launch).
         auto step = [&](auto fuse_tag, half8 (&af)[4], uint32_t& poll, int s, int it_prev) __attribute__((always_inline)) {
             constexpr bool FUSE = decltype(fuse_tag)::value;
-            // my corpus fragments of this step have landed (issued two steps ago); the V operations of the previous step
-            // stay in flight. No barrier here: the query image of step s was certified by the mid-step barrier of step s-1.
-            wait_vmcnt_keep<V>(af);
+            // my corpus fragments of this step have landed (issued AD steps ago); the V operations of each of the AD-1
+            // steps since stay in flight. No barrier here: the query image of step s was certified by the mid-step barrier of step s-1.
+            wait_vmcnt_keep<V*(AD - 1)>(af);
             if constexpr (SIB) {
                 asm volatile("" : "+v"(poll));   // the snapshot requested two steps ago has landed with the fragments
                 if (sib_on && sib_lag(__builtin_amdgcn_readfirstlane(poll), s) > p.sib_lag) {
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
             const int ksn = ks + 1 == KS ? 0 : ks + 1;
             const char* st = smem + (RES ? ks : slot_c) * B_BYTES;
             const char* stn = smem + (RES ? ksn : ((slot_c + 1) & 3)) * B_BYTES;   // image of step s+1
-            const bool more = s + 2 < total;   // step s+2 exists; otherwise re-read this stream's first step (never used)
+            const bool more = s + AD < total;   // step s+AD exists; otherwise re-read this stream's first step (never used)
             const char* an = a_src(more ? it2 : 0, more ? ks2 : 0);
             float tq_cur = 0.f;   // FUSE: this lane's threshold for the next block to check, fetched one block ahead
             int tb = l15 * NB16;
@@ -595,20 +596,47 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
             }
             epilogue(my_tiles - 1);
         } else {
-            for (; s + 1 < total; s += 2) {
-                step(std::false_type{}, a0, poll0, s, 0);
-                advance(s);
-                step(std::false_type{}, a1, poll1, s + 1, 0);
-                advance(s + 1);
-            }
-            if (s < total) {
-                step(std::false_type{}, a0, poll0, s, 0);
-                advance(s);
+            if constexpr (AD == 4) {
+                for (; s + 3 < total; s += 4) {
+                    step(std::false_type{}, a0, poll0, s, 0);
+                    advance(s);
+                    step(std::false_type{}, a1, poll1, s + 1, 0);
+                    advance(s + 1);
+                    step(std::false_type{}, a2, poll0, s + 2, 0);
+                    advance(s + 2);
+                    step(std::false_type{}, a3, poll1, s + 3, 0);
+                    advance(s + 3);
+                }
+                if (s < total) {
+                    step(std::false_type{}, a0, poll0, s, 0);
+                    advance(s);
+                    if (s + 1 < total) {
+                        step(std::false_type{}, a1, poll1, s + 1, 0);
+                        advance(s + 1);
+                        if (s + 2 < total) {
+                            step(std::false_type{}, a2, poll0, s + 2, 0);
+                            advance(s + 2);
+                        }
+                    }
+                }
+            } else {
+                for (; s + 1 < total; s += 2) {
+                    step(std::false_type{}, a0, poll0, s, 0);
+                    advance(s);
+                    step(std::false_type{}, a1, poll1, s + 1, 0);
+                    advance(s + 1);
+                }
+                if (s < total) {
+                    step(std::false_type{}, a0, poll0, s, 0);
+                    advance(s);
+                }
             }
         }
         // drain the never-consumed tail prefetches; naming all eight fragments keeps their registers reserved until here
         asm volatile("s_waitcnt vmcnt(0)" ::"v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3])
                      : "memory");
+        if constexpr (AD == 4)
+            asm volatile("" ::"v"(a2[0]), "v"(a2[1]), "v"(a2[2]), "v"(a2[3]), "v"(a3[0]), "v"(a3[1]), "v"(a3[2]), "v"(a3[3]));
         if constexpr (SIB) asm volatile("" ::"v"(poll0), "v"(poll1));
     }
 
