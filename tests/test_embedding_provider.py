@@ -57,3 +57,97 @@ def test_embed_device_feeds_the_index_without_the_list_round_trip(oracle):
     sa, sb = a.search(q, 5), b.search(q, 5)
     np.testing.assert_array_equal(sa[1], sb[1])
     assert p.embed_device([]).shape == (0, p.dims)
+
+
+# ---- the real-checkpoint branch of load(): a LOCAL directory with config + weights + tokenizer files -----------------------
+# No BGE-M3 weights exist offline, so the checkpoint is built here: a sentencepiece unigram model trained on a small synthetic
+# corpus, wrapped as an XLM-RoBERTa tokenizer, and a 2-layer XLM-R with random weights, both written with save_pretrained —
+# the directory layout `BAAI/bge-m3` has. What this pins is the PIPELINE (char-truncate -> HF tokenizer -> XLM-R forward -> CLS
+# pooling -> L2 normalise, reference src/utils/embedding_provider.py:118-147) against a plain fp32 transformers forward of the
+# same checkpoint; the VALUES of BGE-M3 itself stay unpinned.
+
+def make_local_checkpoint(path):
+    import random
+    import sentencepiece as spm
+    import torch
+    from transformers import XLMRobertaConfig, XLMRobertaModel, XLMRobertaTokenizer
+    os_ = __import__("os")
+    os_.makedirs(path, exist_ok=True)
+    words = ("durée conservation données personnelles traitement registre sous-traitant responsable AIPD analyse impact "
+             "consentement cookies traceurs vidéosurveillance salariés transfert hors union européenne violation notification "
+             "CNIL délégué protection base légale intérêt légitime droit accès effacement portabilité sanction mise en demeure "
+             "sécurité Quelle Comment des de la le une faire").split()
+    rnd = random.Random(0)
+    txt = os_.path.join(path, "corpus.txt")
+    with open(txt, "w", encoding="utf-8") as f:
+        for _ in range(3000):
+            f.write(" ".join(rnd.choice(words) for _ in range(rnd.randint(5, 30))) + " ?\n")
+    spm.SentencePieceTrainer.train(input=txt, model_prefix=os_.path.join(path, "spm"), vocab_size=150, model_type="unigram",
+                                   character_coverage=1.0, hard_vocab_limit=False, minloglevel=2)
+    sp = spm.SentencePieceProcessor(model_file=os_.path.join(path, "spm.model"))
+    pieces = [(sp.id_to_piece(i), sp.get_score(i)) for i in range(sp.get_piece_size()) if not (sp.is_control(i) or sp.is_unknown(i))]
+    vocab = [("<s>", 0.0), ("<pad>", 0.0), ("</s>", 0.0), ("<unk>", 0.0)] + pieces + [("<mask>", 0.0)]   # XLM-R's id layout
+    tok = XLMRobertaTokenizer(vocab=vocab)
+    ckpt = os_.path.join(path, "bge-m3-local")
+    tok.save_pretrained(ckpt)
+    torch.manual_seed(0)
+    cfg = XLMRobertaConfig(vocab_size=len(vocab), hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                           max_position_embeddings=514, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    XLMRobertaModel(cfg, add_pooling_layer=False).save_pretrained(ckpt)
+    return ckpt
+
+
+TEXTS = ["Comment faire une AIPD ?", "durée de conservation des données personnelles", "registre", "",
+         "Quelle sanction la CNIL ? " * 40, "transfert hors union européenne", "cookies traceurs consentement"]
+
+
+def hf_reference(ckpt, texts):
+    """plain transformers, fp32, CPU: tokenizer -> forward -> CLS, one text at a time (no padding involved)"""
+    import torch
+    from transformers import AutoTokenizer, XLMRobertaModel
+    tok = AutoTokenizer.from_pretrained(ckpt, local_files_only=True)
+    model = XLMRobertaModel.from_pretrained(ckpt, add_pooling_layer=False, local_files_only=True).eval()
+    out = []
+    with torch.no_grad():
+        for t in texts:
+            enc = tok([t], padding=True, truncation=True, max_length=EP.MAX_SEQ_LENGTH, return_tensors="pt")
+            out.append(model(**enc).last_hidden_state[0, 0].to(torch.float32).numpy())
+    return np.stack(out), tok
+
+
+def test_local_checkpoint_branch_cpu(tmp_path):
+    import torch
+    ckpt = make_local_checkpoint(str(tmp_path))
+    ref, tok = hf_reference(ckpt, TEXTS)
+    ids = tok(TEXTS[1])["input_ids"]
+    assert len(ids) > 4 and tok.unk_token_id not in ids                    # a real subword tokenizer, not the hashing stand-in
+    # model_name = the directory itself; and <cache_dir>/<name> as the reference passes cache_dir (embedding_provider.py:87-92)
+    for kw in (dict(model_name=ckpt), dict(model_name="bge-m3-local", cache_dir=str(tmp_path))):
+        p = EP.EmbeddingProvider(device="cpu", dtype=torch.float32, batch_size=3, **kw)
+        assert p.load() is p and p.is_loaded and p.dims == 64
+        assert not isinstance(p._tokenizer, EP._HashTokenizer)
+        raw = p._encode_raw(TEXTS).numpy()                                  # length-sorted batches of 3, padded, back in input order
+        np.testing.assert_allclose(raw, ref, rtol=0, atol=2e-5)            # padding + batching change nothing beyond fp32 noise
+        assert p.embed_device(TEXTS[:2]).shape == (2, 64)
+        with pytest.raises(Exception, match="librdx|MI355X|GPU"):
+            p.embed(TEXTS)                                                  # the normalise step runs in librdx: no CPU path
+        p.unload()
+
+
+@pytest.mark.gpu
+def test_local_checkpoint_embed_matches_fp32_reference(tmp_path, oracle):
+    """embed() on the GPU (fp16 forward, K1 normalise) against the fp32 transformers forward + oracle normalise of the same local
+    checkpoint: unit rows, cosine to the reference row > 0.9999, max abs difference 3e-3 (fp16 forward of a 2-layer model)"""
+    import torch
+    ckpt = make_local_checkpoint(str(tmp_path))
+    ref, _ = hf_reference(ckpt, TEXTS)
+    ref_hat = oracle.normalize_rows(ref)
+    p = EP.EmbeddingProvider(model_name=ckpt, device="cuda", dtype=torch.float16, batch_size=4)
+    out = np.asarray(p.embed(TEXTS), dtype=np.float32)
+    assert out.shape == (len(TEXTS), 64)
+    assert np.abs(np.linalg.norm(out.astype(np.float64), axis=1) - 1).max() < 1e-6
+    assert (np.sum(out * ref_hat, axis=1) > 0.9999).all()
+    assert np.abs(out - ref_hat).max() < 3e-3
+    p32 = EP.EmbeddingProvider(model_name=ckpt, device="cuda", dtype=torch.float32, batch_size=4)
+    out32 = np.asarray(p32.embed(TEXTS), dtype=np.float32)
+    assert np.abs(out32 - ref_hat).max() < 2e-5                             # fp32 on the GPU: the same pipeline to fp32 noise
