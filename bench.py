@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="developer: rdx_index_set_option before the run")
     ap.add_argument("--fp32-master", action="store_true", help="c5: keep the normalised fp32 rows as the exact copy (6 instead of 4 B/element)")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel of a search (path_stats.ms), not only the main scan")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N=1: initialise torch.distributed (nccl = RCCL) anyway and run the all-gather + merge with world 1 "
+                         "(the exchange path on the real backend when only one GPU is there)")
     ap.add_argument("--check-merged", action="store_true",
                     help="N>1: rank 0 also builds the WHOLE corpus in one index and checks that the merged result is bit-identical")
     args = ap.parse_args()
@@ -215,7 +218,11 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 or args.force_dist:
+        if args.force_dist and "RANK" not in os.environ:     # plain `python bench.py --force-dist`: a one-rank group in this process
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -237,7 +244,7 @@ def main():
         shard.index.set_option("compact_master", 1)   # config 5: raw bf16 rows + divisors as the exact copy: 4 B/element in HBM
     build_shard(shard, lo, hi, dim, wl["corpus"], device, rows)
     log(f"[rank {rank}] shard rows [{lo}, {hi}) resident in {time.time() - t_build:.1f}s")
-    searcher = ShardedSearcher(shard, host_staged=rehearsal)
+    searcher = ShardedSearcher(shard, host_staged=rehearsal, always_exchange=args.force_dist)
     queries, planted = synth.torch_queries(B, dim, device, total_rows=rows, return_planted=True)   # 10 % planted (§8d)
     # HIP events on the stream the kernels run on: 2 = around the dominant kernel (the main scan) only, which is what the
     # timed region carries; --profile-all records every kernel boundary (7 events per search: visible in small configs)
@@ -500,7 +507,7 @@ def main():
                            "ms": {n_: round(stats[n_], 4) for n_ in ("ms_normalize", "ms_scan_sample", "ms_tau", "ms_scan_main",
                                                                      "ms_refine", "ms_exact")}},
         }
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:

@@ -54,6 +54,20 @@ def _devices_from_env() -> Optional[List[int]]:
     return [int(x) for x in v.split(",") if x.strip() != ""]
 
 
+def _fsync_dir(path: str):
+    """make a rename / file creation in `path` durable (the directory entry itself)"""
+    try:
+        fd = os.open(path, os.O_RDONLY)
+    except OSError:
+        return
+    try:
+        os.fsync(fd)
+    except OSError:
+        pass
+    finally:
+        os.close(fd)
+
+
 def _is_device_tensor(x) -> bool:
     import sys
     torch = sys.modules.get("torch")
@@ -557,6 +571,7 @@ class Collection:
             f.flush()
             os.fsync(f.fileno())
         os.replace(tmp, os.path.join(path, "collection.json"))
+        _fsync_dir(path)
 
     def _log(self, rec: dict, emb):
         if not self._dir or self._replaying:
@@ -601,6 +616,7 @@ class Collection:
                                        ensure_ascii=False) + "\n")
                 f.flush()
                 os.fsync(f.fileno())
+            _fsync_dir(path)                      # the new generation's files exist before the header can name them
             self._write_header(path, n)          # commit point: the header names generation g+1
             self._snap_rows = n
             for fn in old.values():

@@ -59,10 +59,12 @@ class ShardedSearcher:
     """`shard` provides search(queries, k, out_score, out_row, out_count) answering with GLOBAL row ids and
     merge_packed(...) over the all-gather receive buffer."""
 
-    def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device=None, host_staged: bool = False):
+    def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device=None, host_staged: bool = False,
+                 always_exchange: bool = False):
         self.shard = shard
         self.group = group
         self.host_staged = host_staged
+        self.always_exchange = always_exchange   # world 1: still run the all-gather + merge (exercises RCCL on a one-GPU box)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = device if device is not None else getattr(shard, "device", torch.device("cpu"))
@@ -107,7 +109,7 @@ class ShardedSearcher:
         per_pad, local, allb, out = self._buffers(nq, k)
         s, r, c = self.views(local, nq, k)
         self.shard.search(queries, k, s, r, c)
-        if self.world == 1:
+        if self.world == 1 and not (self.always_exchange and dist.is_initialized()):
             return s, r, c
         if self.host_staged:
             # rehearsal only (several ranks sharing ONE GPU over gloo, which cannot move device memory): same packed
