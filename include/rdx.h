@@ -138,6 +138,17 @@ int rdx_mask_destroy(rdx_mask* m);
 int rdx_search_masked(rdx_index* h, const float* queries, int64_t nq, int k, const rdx_mask* mask, float* out_score,
                       int64_t* out_row, int32_t* out_count, int space, void* stream);
 
+/* The search in two halves, for callers that enqueue consumers of the results on the same stream (the multi-GPU path: the
+ * RCCL all-gather of the partial top-k and the merge, reference has no counterpart). rdx_search_async enqueues the whole
+ * search (device pointers only, nq <= 4096; mask may be NULL) and returns without waiting; rdx_search_wait blocks until that
+ * search has completed and runs its host half: when some queries' candidate segments overflowed (rare: clustered corpora) it
+ * re-runs them through the fallback passes, synchronises the stream and reports *redone = 1 — results written by the first
+ * pass were incomplete for those queries, so whatever consumed them on the stream must be re-enqueued. Any other call on
+ * the index completes a pending search first. rdx_search == rdx_search_async + rdx_search_wait for device callers. */
+int rdx_search_async(rdx_index* h, const float* queries, int64_t nq, int k, const rdx_mask* mask, float* out_score,
+                     int64_t* out_row, int32_t* out_count, void* stream);
+int rdx_search_wait(rdx_index* h, int* redone);
+
 /* Multi-GPU exchange step: merge n_parts per-shard partial results (after the RCCL all-gather,
  * SURVEY.md §8e) into the global top-k with the same ordering rule. Layouts:
  * part_score/part_row [n_parts][nq][k], part_count [n_parts][nq]; row ids must already be global. */

@@ -69,6 +69,8 @@ SYMBOLS = {
     "rdx_mask_create": (_i, [_vp, _vp, _i, ctypes.POINTER(_vp)]),
     "rdx_mask_destroy": (_i, [_vp]),
     "rdx_search_masked": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "rdx_search_async": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rdx_search_wait": (_i, [_vp, ctypes.POINTER(_i)]),
     "rdx_merge_topk": (_i, [_i, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _vp]),
     "rdx_merge_topk_packed": (_i, [_i, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "rdx_search_last_stats": (_i, [_vp, ctypes.POINTER(SearchStats)]),

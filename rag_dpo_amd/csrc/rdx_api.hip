@@ -83,6 +83,36 @@ struct DevBuf {
     ~DevBuf() { release(); }   // error paths that return early do not leak scratch
 };
 
+// Host callers: where the results go (see search_chunk)
+struct HostOut {
+    float* score;
+    int64_t* row;
+    int32_t* count;
+    bool stale;
+};
+
+// A search whose kernels (up to k_finish) are enqueued and whose host half — waiting for the mailbox, copying small
+// results out, re-weighting the XCD shares, the fallback passes for overflowed queries, the statistics — has not run yet.
+// rdx_search runs that half at once; rdx_search_async leaves it to rdx_search_wait, so that the caller can enqueue what
+// consumes the results (the RCCL all-gather and the merge) while the scan is still running.
+struct PendingSearch {
+    bool active = false;
+    const float* d_queries = nullptr;
+    int64_t nq = 0;
+    int k = 0;
+    const uint32_t* d_allow = nullptr;
+    float* d_score = nullptr;
+    int64_t* d_row = nullptr;
+    int32_t* d_count = nullptr;
+    hipStream_t st = nullptr;
+    unsigned long long seq = 0;
+    bool exact_only = false, balance = false, ride = false, big_host_copy = false;
+    int grid = 0, G = 0, nqt = 0, depth = 0;
+    int64_t sample_rows = 0;
+    size_t b_s = 0, b_r = 0, b_c = 0;
+    rdx_search_stats stats = {};   // rdx_search_async only: the statistics of the deferred search
+};
+
 // ------------------------------------------------------------------------------------------------
 // the index: one corpus shard resident in one GPU's HBM
 // ------------------------------------------------------------------------------------------------
@@ -123,6 +153,7 @@ struct rdx_index {
     char* pin_out_dev = nullptr;
     size_t pin_out_bytes = 0;
     bool ctr_ready = false;           // the counter block was zeroed once; afterwards every k_finish re-zeroes it
+    PendingSearch pending;            // rdx_search_async: the search whose host half is still to run
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
     rdx_search_stats stats = {};
@@ -137,6 +168,8 @@ struct rdx_mask {
     int64_t rows = 0;   // row count of the index when the mask was made: a mask never outlives a write to the index
     DevBuf words;
 };
+
+static int finish_pending(rdx_index* h, bool* redone);   // (search section)
 
 static size_t shadow_bytes(const rdx_index* h, int64_t cap) { return (size_t)cap * h->dim_pad * 2; }
 
@@ -272,6 +305,7 @@ extern "C" int rdx_index_create(int device, int dim, rdx_index** out) {
 extern "C" int rdx_index_destroy(rdx_index* h) {
     if (!h) return RDX_OK;
     (void)hipSetDevice(h->device);
+    if (h->pending.active) (void)hipStreamSynchronize(h->pending.st);   // an abandoned asynchronous search: let its kernels finish
     (void)hipStreamSynchronize(h->own_stream);
     free_master(h->master, h->raw16, h->den);
     if (h->shadow) (void)hipFree(h->shadow);
@@ -386,6 +420,7 @@ static int add_impl(rdx_index* h, const void* rows, bool is_bf16, int64_t n, int
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (n == 0) return RDX_OK;
     std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(finish_pending(h, nullptr));
     if (h->compact && (!is_bf16 || verbatim))
         return fail(RDX_ERR_STATE, "this index keeps a compact master (raw bf16 rows + divisors): rows must arrive through rdx_index_add_bf16");
     RDX_TRY(set_device(h));
@@ -433,6 +468,7 @@ extern "C" int rdx_index_update(rdx_index* h, const int64_t* row_ids, const floa
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (n == 0) return RDX_OK;
     std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(finish_pending(h, nullptr));
     if (h->compact) return fail(RDX_ERR_STATE, "rdx_index_update takes fp32 rows: not available on an index with a compact (bf16) master");
     RDX_TRY(set_device(h));
     const int64_t* d_ids = nullptr;
@@ -470,6 +506,7 @@ extern "C" int rdx_index_get(rdx_index* h, const int64_t* row_ids, int64_t n, fl
 extern "C" int rdx_index_compact(rdx_index* h, const int64_t* keep, int64_t n_keep) {
     if (!h || n_keep < 0 || (n_keep > 0 && !keep)) return fail(RDX_ERR_INVALID, "rdx_index_compact: bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(finish_pending(h, nullptr));
     RDX_TRY(set_device(h));
     for (int64_t i = 0; i < n_keep; ++i) {
         if (keep[i] < 0 || keep[i] >= h->rows) return fail(RDX_ERR_INVALID, "compact: row id out of range");
@@ -656,16 +693,9 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
     return RDX_OK;
 }
 
-// Host callers: where the results go. Small results travel with the end-of-search kernel into pinned staging and are
-// copied to the caller's buffers by the CPU once the mailbox says the search is complete; large ones use D2H copies.
-// When a fallback pass had to rewrite some results afterwards they are copied again (HostOut::stale).
-struct HostOut {
-    float* score;
-    int64_t* row;
-    int32_t* count;
-    bool stale;
-};
-
+// Host callers (HostOut): small results travel with the end-of-search kernel into pinned staging and are copied to the
+// caller's buffers by the CPU once the mailbox says the search is complete; large ones use D2H copies. When a fallback pass
+// had to rewrite some results afterwards they are copied again (HostOut::stale).
 static const size_t PIN_MAX = 256 * 1024;   // results up to this size ride with k_finish (one block writing over PCIe)
 
 static int ensure_mailbox(rdx_index* h) {
@@ -720,9 +750,12 @@ static int wait_search(rdx_index* h, hipStream_t st, unsigned long long seq) {
 }
 
 // depth 0 = the caller's batch; depth 1 = the second-chance batch of queries whose candidate segments overflowed
+static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stats* acc_stats, HostOut* ho, bool* redone);
+
+// `defer`: return as soon as everything up to k_finish is enqueued; the host half is left in h->pending (rdx_search_async)
 static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k, const uint32_t* d_allow, float* d_score,
                         int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth = 0,
-                        HostOut* ho = nullptr) {
+                        HostOut* ho = nullptr, bool defer = false) {
     const int nq_pad = (int)((nq + 255) / 256 * 256);
     const bool prof_all = h->profile == 1 && depth == 0, prof_main = h->profile != 0 && depth == 0;
     auto mark = [&](int i) {
@@ -897,8 +930,57 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
                        reinterpret_cast<const uint32_t*>(d_score), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r), (int64_t)(ride ? b_s / 4 : 0),
                        reinterpret_cast<const uint32_t*>(d_count), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r + b_s), (int64_t)(ride ? b_c / 4 : 0));
     HIP_TRY(hipGetLastError());
-    if (ho && !ride) HIP_TRY(hipStreamSynchronize(st));   // pageable D2H copies: complete only after a stream synchronise
-    RDX_TRY(wait_search(h, st, seq));   // the ONE host wait of a search
+    PendingSearch ps;
+    ps.active = true;
+    ps.d_queries = d_queries;
+    ps.nq = nq;
+    ps.k = k;
+    ps.d_allow = d_allow;
+    ps.d_score = d_score;
+    ps.d_row = d_row;
+    ps.d_count = d_count;
+    ps.st = st;
+    ps.seq = seq;
+    ps.exact_only = exact_only;
+    ps.balance = balance;
+    ps.ride = ride;
+    ps.big_host_copy = ho && !ride;
+    ps.grid = grid;
+    ps.G = G;
+    ps.nqt = nqt;
+    ps.depth = depth;
+    ps.sample_rows = sample_rows;
+    ps.b_s = b_s;
+    ps.b_r = b_r;
+    ps.b_c = b_c;
+    if (defer) {
+        ps.stats = *acc_stats;
+        h->pending = ps;
+        return RDX_OK;
+    }
+    return complete_chunk(h, ps, acc_stats, ho, nullptr);
+}
+
+// the host half of a search (see PendingSearch). *redone (if given) = a fallback pass rewrote results after k_finish.
+static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stats* acc_stats, HostOut* ho, bool* redone) {
+    const float* d_queries = ps.d_queries;
+    const int64_t nq = ps.nq;
+    const int k = ps.k, depth = ps.depth, grid = ps.grid, G = ps.G, nqt = ps.nqt;
+    const uint32_t* d_allow = ps.d_allow;
+    float* d_score = ps.d_score;
+    int64_t* d_row = ps.d_row;
+    int32_t* d_count = ps.d_count;
+    hipStream_t st = ps.st;
+    const bool exact_only = ps.exact_only, balance = ps.balance, ride = ps.ride;
+    const int64_t sample_rows = ps.sample_rows;
+    const size_t b_s = ps.b_s, b_r = ps.b_r, b_c = ps.b_c;
+    const bool prof_all = h->profile == 1 && depth == 0, prof_main = h->profile != 0 && depth == 0;
+    auto mark = [&](int i) {
+        if (prof_all || (prof_main && (i == 3 || i == 4))) (void)hipEventRecord(h->ev[i], st);
+    };
+    if (redone) *redone = false;
+    if (ps.big_host_copy) HIP_TRY(hipStreamSynchronize(st));   // pageable D2H copies: complete only after a stream synchronise
+    RDX_TRY(wait_search(h, st, ps.seq));   // the ONE host wait of a search
     const Mailbox& mb = *h->mbox;
     const unsigned long long c_emitted = mb.emitted, c_rescored = mb.rescored;
     const int c_bad = mb.bad;
@@ -911,6 +993,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         }
         std::memcpy(ho->count, h->pin_out + b_r + b_s, b_c);
     }
+    if (!exact_only && n_exact > 0 && !c_bad && redone) *redone = true;
     if (!exact_only) {
         if (n_exact > 0 && ho) ho->stale = true;   // a fallback pass rewrites some of the rows copied above
         if (balance) {   // the stamps arrived with the counters: re-weight the XCD shares for the next search
@@ -1001,6 +1084,19 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     return RDX_OK;
 }
 
+// run the host half of a search left pending by rdx_search_async (call with h->mu held)
+static int finish_pending(rdx_index* h, bool* redone) {
+    if (redone) *redone = false;
+    if (!h->pending.active) return RDX_OK;
+    PendingSearch ps = h->pending;
+    h->pending.active = false;
+    RDX_TRY(set_device(h));
+    rdx_search_stats s = ps.stats;
+    const int rc = complete_chunk(h, ps, &s, nullptr, redone);
+    h->stats = s;
+    return rc;
+}
+
 // allow_resident: allow_bits is already device memory whatever `space` says (a resident rdx_mask)
 static int search_impl(rdx_index* h, const float* queries, int64_t nq, int k, const uint32_t* allow_bits, bool allow_resident,
                        float* out_score, int64_t* out_row, int32_t* out_count, int space, void* stream) {
@@ -1010,6 +1106,7 @@ static int search_impl(rdx_index* h, const float* queries, int64_t nq, int k, co
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (nq == 0) return RDX_OK;
     if (!queries || !out_count || (k > 0 && (!out_score || !out_row))) return fail(RDX_ERR_INVALID, "rdx_search: null pointer");
+    RDX_TRY(finish_pending(h, nullptr));   // scratch buffers are shared: an asynchronous search completes first
     RDX_TRY(set_device(h));
     // device pointers: the caller's stream as given (NULL = the default stream the caller produced its inputs on)
     hipStream_t st = (space == RDX_DEVICE || stream) ? (hipStream_t)stream : h->own_stream;
@@ -1071,6 +1168,37 @@ extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k,
     if (!h) return fail(RDX_ERR_INVALID, "rdx_search: null index");
     std::lock_guard<std::mutex> lk(h->mu);
     return search_impl(h, queries, nq, k, allow_bits, false, out_score, out_row, out_count, space, stream);
+}
+
+extern "C" int rdx_search_async(rdx_index* h, const float* queries, int64_t nq, int k, const rdx_mask* mask, float* out_score,
+                                int64_t* out_row, int32_t* out_count, void* stream) {
+    if (!h) return fail(RDX_ERR_INVALID, "rdx_search_async: null index");
+    if (nq < 1 || nq > 4096 || k < 0 || k > SELECT_MAX_K) return fail(RDX_ERR_INVALID, "rdx_search_async: 1 <= nq <= 4096, 0 <= k <= " + std::to_string(SELECT_MAX_K));
+    if (!queries || !out_count || (k > 0 && (!out_score || !out_row))) return fail(RDX_ERR_INVALID, "rdx_search_async: null pointer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (mask && (mask->device != h->device || mask->rows != h->rows))
+        return fail(RDX_ERR_STATE, "rdx_search_async: the mask was made for another state of the index");
+    RDX_TRY(finish_pending(h, nullptr));
+    RDX_TRY(set_device(h));
+    if (h->profile && !h->ev_ok) {
+        for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+        h->ev_ok = true;
+    }
+    rdx_search_stats s = {};
+    s.nq = nq;
+    s.k = k;
+    s.rows = h->rows;
+    return search_chunk(h, queries, nq, k, mask ? mask->words.as<uint32_t>() : nullptr, out_score, out_row, out_count, (hipStream_t)stream, &s, 0,
+                        nullptr, true);
+}
+
+extern "C" int rdx_search_wait(rdx_index* h, int* redone) {
+    if (!h) return fail(RDX_ERR_INVALID, "rdx_search_wait: null index");
+    std::lock_guard<std::mutex> lk(h->mu);
+    bool r = false;
+    const int rc = finish_pending(h, &r);
+    if (redone) *redone = r ? 1 : 0;
+    return rc;
 }
 
 extern "C" int rdx_mask_create(rdx_index* h, const uint32_t* allow_bits, int space, rdx_mask** out) {

@@ -48,6 +48,16 @@ class HipShard:
     def search(self, queries: torch.Tensor, k: int, out_score, out_row, out_count):
         self.index.search_device(queries, k, out_score, out_row, out_count)
 
+    def search_async(self, queries: torch.Tensor, k: int, out_score, out_row, out_count) -> bool:
+        """enqueue only (rdx_search_async); False when the batch is too large for the asynchronous form"""
+        if queries.shape[0] > 4096:
+            return False
+        self.index.search_device_async(queries, k, out_score, out_row, out_count)
+        return True
+
+    def search_wait(self) -> bool:
+        return self.index.search_wait()
+
     def merge_packed(self, packed: torch.Tensor, part_stride: int, n_parts: int, nq: int, k: int, out_score, out_row, out_count):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         p = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -108,8 +118,15 @@ class ShardedSearcher:
                 dist.broadcast(queries, src=query_src, group=self.group)
         per_pad, local, allb, out = self._buffers(nq, k)
         s, r, c = self.views(local, nq, k)
-        self.shard.search(queries, k, s, r, c)
+        # The shard's search is ENQUEUED, the exchange step is enqueued right behind it on the same stream, and only then does
+        # the host wait for the search (rdx_search_wait): the host-side cost of launching the collective overlaps the scan
+        # instead of leaving the GPU idle after it. If the search had to re-run overflowed queries (rare) the exchange is repeated.
+        deferred = hasattr(self.shard, "search_async") and self.shard.search_async(queries, k, s, r, c)
+        if not deferred:
+            self.shard.search(queries, k, s, r, c)
         if self.world == 1 and not (self.always_exchange and dist.is_initialized()):
+            if deferred:
+                self.shard.search_wait()
             return s, r, c
         if self.host_staged:
             # rehearsal only (several ranks sharing ONE GPU over gloo, which cannot move device memory): same packed
@@ -121,4 +138,22 @@ class ShardedSearcher:
         else:
             dist.all_gather_into_tensor(allb, local, group=self.group)   # the ONE exchange step (RCCL over xGMI)
         self.shard.merge_packed(allb, per_pad, self.world, nq, k, out[0], out[1], out[2])
+        if deferred and self._any_redone(self.shard.search_wait()):
+            # some rank's fallback passes rewrote its partial after the first exchange: exchange and merge again
+            if self.host_staged:
+                h_all = torch.empty(self.world * per_pad, dtype=torch.uint8)
+                dist.all_gather_into_tensor(h_all, local.cpu(), group=self.group)
+                allb.copy_(h_all)
+            else:
+                dist.all_gather_into_tensor(allb, local, group=self.group)
+            self.shard.merge_packed(allb, per_pad, self.world, nq, k, out[0], out[1], out[2])
         return out
+
+    def _any_redone(self, mine: bool) -> bool:
+        """every rank must take the same branch: a one-int all-reduce, only when the asynchronous form is in use. The common
+        answer (nobody) costs one tiny collective per search; ranks whose searches never overflow still pay it."""
+        if self.world == 1:
+            return mine
+        flag = torch.tensor([1 if mine else 0], dtype=torch.int32, device="cpu" if self.host_staged else self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(flag.item())

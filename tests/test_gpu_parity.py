@@ -81,6 +81,39 @@ def test_baseline_config2(eng, oracle):
     ix.close()
 
 
+def test_search_in_two_halves(eng, oracle):
+    """rdx_search_async + rdx_search_wait (the form the multi-GPU exchange uses): same results as rdx_search; when candidate
+    segments overflow the wait runs the fallback passes and reports it; a following call completes a pending search itself"""
+    import torch
+    corpus = synth.make_corpus(40_000, 1024)
+    q = synth.make_queries(130, 1024, corpus)
+    es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, 50)
+    ix = _index(eng, corpus, force_fast=1)
+    qd = torch.from_numpy(q).cuda()
+    s = torch.empty((130, 50), dtype=torch.float32, device="cuda"); r = torch.empty((130, 50), dtype=torch.int64, device="cuda")
+    c = torch.empty((130,), dtype=torch.int32, device="cuda")
+
+    def check():
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(r.cpu().numpy(), er); np.testing.assert_array_equal(s.cpu().numpy(), es)
+        np.testing.assert_array_equal(c.cpu().numpy(), ec)
+    ix.search_device_async(qd, 50, s, r, c)
+    assert ix.search_wait() is False and ix.last_stats()["exact_queries"] == 0
+    check()
+    assert ix.search_wait() is False                       # nothing pending: a no-op
+    ix.set_option("cand_cap", 8)                           # 8 slots per segment cannot hold k = 50: overflow -> fallback passes
+    s.zero_(); r.zero_(); c.zero_()
+    ix.search_device_async(qd, 50, s, r, c)
+    assert ix.search_wait() is True
+    check()
+    s.zero_(); r.zero_(); c.zero_()
+    ix.search_device_async(qd, 50, s, r, c)                # never waited for: the next call on the index completes it first
+    gs, gr, gc = ix.search(q[:7], 50)
+    np.testing.assert_array_equal(gr, er[:7])
+    check()
+    ix.close()
+
+
 def test_fused_epilogue_variant(eng, oracle):
     """option fuse_epilogue: the B > 128 main scan whose emit check rides in the next tile's first k-step — several tiles per
     stream (so that the fused step runs), a ragged last tile, a row bitmap, planted near-duplicates, both against the oracle"""

@@ -45,6 +45,33 @@ class OracleShard:
         out_score.copy_(torch.from_numpy(s)); out_row.copy_(torch.from_numpy(r)); out_count.copy_(torch.from_numpy(c))
 
 
+class DeferredOracleShard(OracleShard):
+    """test double of the ASYNCHRONOUS form (HipShard.search_async / search_wait): the first pass leaves the partial of the
+    queries in `late` empty, as an overflowed query's is until its fallback pass has run; search_wait() completes them and
+    says so on the ranks where that happened — the exchange must then be repeated on EVERY rank"""
+
+    def __init__(self, corpus_hat, row_offset, late):
+        super().__init__(corpus_hat, row_offset)
+        self.late, self.pending, self.waits = late, None, 0
+
+    def search_async(self, queries, k, out_score, out_row, out_count):
+        OracleShard.search(self, queries, k, out_score, out_row, out_count)
+        self.pending = None
+        if len(self.late):
+            self.pending = (out_score[self.late].clone(), out_row[self.late].clone(), out_count[self.late].clone(), out_score, out_row, out_count)
+            out_score[self.late] = float("-inf"); out_row[self.late] = -1; out_count[self.late] = 0
+        return True
+
+    def search_wait(self):
+        self.waits += 1
+        if self.pending is None:
+            return False
+        s, r, c, out_score, out_row, out_count = self.pending
+        out_score[self.late] = s; out_row[self.late] = r; out_count[self.late] = c
+        self.pending = None
+        return True
+
+
 def _worker(rank, world, port, n, dim, b, k, out_dir):
     sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -64,6 +91,13 @@ def _worker(rank, world, port, n, dim, b, k, out_dir):
     s, r, c = s.clone(), r.clone(), c.clone()
     s2, r2, c2 = ss.search(q, k)                                    # replicated batch, no broadcast
     assert torch.equal(r, r2) and torch.equal(s, s2) and torch.equal(c, c2)
+    # asynchronous form: rank 1's first pass is incomplete for queries 2 and 5 (every other rank's is complete) — all ranks
+    # must repeat the exchange and end with the same, complete result; with nothing late nobody repeats it
+    for late in ([2, 5], []):
+        sh = DeferredOracleShard(corpus[lo:hi], lo, late if rank == 1 else [])
+        s3, r3, c3 = ShardedSearcher(sh).search(q, k)
+        assert sh.waits == 1
+        assert torch.equal(r, r3) and torch.equal(s, s3) and torch.equal(c, c3), (rank, late)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), c=c.numpy())
     dist.barrier()
     dist.destroy_process_group()
