@@ -213,6 +213,11 @@ def main():
         # it starts the N ranks as a CHILD torch.distributed.run (one process per GPU over RCCL), relays rank 0's JSON
         # line and exits with the child's code. Never an exec from a process that initialised the GPU.
         sys.exit(self_launch(args.gpus))
+    # stdout carries exactly ONE line, the JSON: everything else this process (or a library inside it: RCCL prints its
+    # version banner on stdout) writes to file descriptor 1 goes to stderr from here on
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -511,7 +516,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
