@@ -29,6 +29,9 @@ done
 cd $R
 bash tools/pmc.sh r02sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" > $O/sq_grbm_2Mrows_pmc.txt 2>&1 || echo "pmc failed"
 rm -rf $R/gpurun_out/pmc_r02sq $R/gpurun_out/prof_r02/*/*/*kernel_trace.csv
+python3 bench.py --workload c4 --no-cpu --rows 1250000 --steps 30 --warmup 5 > $O/c4_one_eighth.json 2> /dev/null || echo "one-eighth failed"
+python3 bench.py --workload c4 --no-cpu --rows 1250000 --steps 30 --warmup 5 --force-dist > $O/c4_one_eighth_rccl_world1.json 2> /dev/null || echo "one-eighth rccl failed"
+python3 tools/collection_latency.py 2>/dev/null | grep -v amdgpu > $O/collection_latency.txt
 RDX_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --rows 600000 --steps 3 --warmup 1 --check-merged > $O/rehearse2_selflaunch.json 2> $O/rehearse2.err; echo "self-launch rehearsal rc=$?"
 python3 - <<PY
 import json, glob
