@@ -414,7 +414,9 @@ def main():
                          "hbm_frac_of_8TBs_on_survey_8d_bytes": round(bytes_8d / sec / 1e9 / PEAK_HBM_GBS, 4),
                          "mfma_frac_of_2.5PF": round(flops / sec / 1e12 / PEAK_MFMA_TFLOPS, 4),
                          "traffic_is": "fabric bytes per launch of this kernel from an EARLIER rocprofv3 --pmc run "
-                                       "(2*FETCH_SIZE + WRITE_SIZE, separate passes), not measured in this run",
+                                       "(2*FETCH_SIZE + WRITE_SIZE, separate passes), not measured in this run; at B > 256 the part "
+                                       "above the algorithmic bytes is query-image lines re-fetched from the Infinity Cache, the corpus "
+                                       "crosses the fabric once (profiles/r02/traffic_split_4Mrows_pmc.txt)",
                          "traffic_source": traffic_src})
         if stats and stats["path"] == 1 and exact_ms > 0:
             # small corpora are answered by the exact full scan alone (K5a k_exact_scores + K5b k_select_dense): one fp32 read
