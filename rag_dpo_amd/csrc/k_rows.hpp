@@ -232,19 +232,28 @@ __global__ __launch_bounds__(256) void k_exact_scores(MasterView master, int64_t
     }
 }
 
-// rank entries (score desc, row asc) held in LDS and write the best k; all threads of the block call it
+// rank entries (score desc, row asc) held in LDS and write the best k; all threads of the block call it.
+// Wave-parallel: a wave takes entry i, its lanes take the entries j it is compared with (64 at a time), the rank is the
+// population count of the ballots — p/64 LDS reads per entry instead of p dependent ones per thread (p = 50: 5.2 -> ~1 us in
+// k_select_dense; the same routine ends k_refine and k_merge).
 __device__ __forceinline__ void rank_and_write(const float* __restrict__ s, const int64_t* __restrict__ r, int p, int k,
                                                float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                int32_t* __restrict__ out_count) {
-    for (int i = threadIdx.x; i < p; i += blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i = wave; i < p; i += nw) {
         const float si = s[i];
         const int64_t ri = r[i];
         int rank = 0;
-        for (int j = 0; j < p; ++j) {
-            const float sj = s[j];
-            rank += (sj > si) || (sj == si && r[j] < ri);
+        for (int j0 = 0; j0 < p; j0 += 64) {
+            const int j = j0 + lane;
+            bool before = false;
+            if (j < p) {
+                const float sj = s[j];
+                before = (sj > si) || (sj == si && r[j] < ri);
+            }
+            rank += __popcll(__ballot(before));
         }
-        if (rank < k) {
+        if (lane == 0 && rank < k) {
             out_score[rank] = si;
             out_row[rank] = ri;
         }
@@ -261,6 +270,12 @@ __device__ __forceinline__ void rank_and_write(const float* __restrict__ s, cons
 // everything above it plus the LOWEST-row entries equal to it (ties -> ascending row id), then a rank sort.
 // -inf marks rows excluded by the `where` pre-filter; they are never returned.
 constexpr int SELECT_MAX_K = 4096;
+#ifdef RDX_SELECT_STAMPS   // developer build (tools/select_stamps.py): where k_select_dense spends its time
+__device__ unsigned long long g_select_stamps[16];
+#define RDX_STAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_select_stamps[i] = wall_clock64(); } while (0)
+#else
+#define RDX_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__ scores, int64_t rows,
                                                        const int32_t* __restrict__ q_list, int k, int64_t row_base,
                                                        const int64_t* __restrict__ row_map,
@@ -280,21 +295,32 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
         rank_and_write(s_s, s_r, 0, k, o_s, o_r, out_count + q);
         return;
     }
+    RDX_STAMP(0);
     const int64_t kk = k < rows ? k : rows;
     int64_t n_gt;
-    // Up to 32 Ki rows the block keeps the whole score row in REGISTERS (32 keys per thread, loaded once: the five passes
-    // below then cost LDS atomics only — measured 30 -> 9 us per query at the reference's 16,919 rows); longer rows are
+    // Up to 32 Ki rows the block keeps the whole score row in REGISTERS (32 keys per thread, loaded once); longer rows are
     // re-read from global memory in every pass.
     constexpr int RN = 32;
     const bool in_regs = rows <= (int64_t)RN * 1024 && blockDim.x == 1024;
     uint32_t kreg[RN];
     if (in_regs) {
+        // unconditional loads (clamped index), all in flight at once: written as "value or padding" the compiler guards every
+        // load with its own branch and waits for each (17 L2 round trips at the reference's 16,919 rows: 5 us)
+        float vreg[RN];
 #pragma unroll
         for (int j = 0; j < RN; ++j) {
             const int64_t i = (int64_t)j * 1024 + threadIdx.x;
-            kreg[j] = i < rows ? f2key(sc[i]) : 0u;   // padding key 0 sorts below every real score (finite or -inf)
+            vreg[j] = sc[i < rows ? i : rows - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < RN; ++j) asm volatile("" : "+v"(vreg[j]));   // the loads stay where they are
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int64_t i = (int64_t)j * 1024 + threadIdx.x;
+            kreg[j] = i < rows ? f2key(vreg[j]) : 0u;   // padding key 0 sorts below every real score (finite or -inf)
         }
     }
+    RDX_STAMP(1);
     const uint32_t kth = in_regs ? block_kth_largest_scan(
                                        [&](auto f) {
 #pragma unroll
@@ -303,6 +329,7 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
                                        },
                                        kk, hist, bc, &n_gt)
                                  : block_kth_largest([&](int64_t i) { return f2key(sc[i]); }, rows, kk, hist, bc, &n_gt);
+    RDX_STAMP(2);
     const int need_eq = (int)(kk - n_gt);   // >= 1
     constexpr int EQ_CAP = 1024;
     __shared__ int64_t eq_idx[EQ_CAP];
@@ -335,6 +362,7 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
         for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) collect(i, f2key(sc[i]));
     }
     __syncthreads();
+    RDX_STAMP(3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if (n_eq <= EQ_CAP) {
         // of the equal entries the need_eq with the LOWEST rows belong to the answer (ties -> ascending row id)
@@ -374,6 +402,7 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
         }
     }
     __syncthreads();
+    RDX_STAMP(4);
     // drop -inf (filtered) entries: they sort last, so count the finite prefix after ranking
     int p = (int)kk;
     __shared__ int n_fin;
@@ -384,7 +413,9 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
     if (loc) atomicAdd(&n_fin, loc);
     __syncthreads();
     const int valid = n_fin;
+    RDX_STAMP(5);
     rank_and_write(s_s, s_r, p, valid < k ? valid : k, o_s, o_r, out_count + q);
+    RDX_STAMP(6);
     // rank_and_write filled [valid, k) only up to its own k argument; pad the rest
     for (int i = valid + threadIdx.x; i < k; i += blockDim.x) {
         o_s[i] = -INFINITY;

@@ -1249,6 +1249,12 @@ extern "C" int rdx_search_masked(rdx_index* h, const float* queries, int64_t nq,
     return search_impl(h, queries, nq, k, mask ? mask->words.as<uint32_t>() : nullptr, true, out_score, out_row, out_count, space, stream);
 }
 
+#ifdef RDX_SELECT_STAMPS
+extern "C" int rdx_debug_select_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(rdx::g_select_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
+
 extern "C" int rdx_search_last_stats(rdx_index* h, rdx_search_stats* out) {
     if (!h || !out) return fail(RDX_ERR_INVALID, "rdx_search_last_stats: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);

@@ -72,9 +72,13 @@ template <class Scan>
 __device__ uint32_t block_kth_largest_scan(Scan scan, int64_t k, uint32_t* hist, uint32_t* bc, int64_t* n_gt) {
     uint32_t prefix = 0, pmask = 0;
     int64_t remaining = k, gt = 0;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    // two workgroup barriers per pass: wave 0 clears each bin right after reading it (the histogram is ready for the next
+    // pass), and nobody overwrites bc[] before the next pass's first barrier
     for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
+        // (measured and dropped: counting the skewed first digit with wave ballots instead of per-key atomics doubles the
+        //  time of the four passes — the ballot / shuffle loop costs more than the queued LDS adds)
         scan([&](uint32_t key) {
             if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         });
@@ -84,6 +88,10 @@ __device__ uint32_t block_kth_largest_scan(Scan scan, int64_t k, uint32_t* hist,
         if (threadIdx.x < 64) {
             const int l = threadIdx.x;
             const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+            hist[4 * l] = 0;
+            hist[4 * l + 1] = 0;
+            hist[4 * l + 2] = 0;
+            hist[4 * l + 3] = 0;
             uint64_t suf = (uint64_t)h0 + h1 + h2 + h3;   // becomes sum over bins >= 4l
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -111,8 +119,8 @@ __device__ uint32_t block_kth_largest_scan(Scan scan, int64_t k, uint32_t* hist,
         pmask |= 255u << shift;
         remaining -= bc[1];
         gt += bc[1];
-        __syncthreads();
     }
+    __syncthreads();
     *n_gt = gt;
     return prefix;
 }
