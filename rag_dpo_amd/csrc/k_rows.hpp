@@ -281,7 +281,7 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
                                                        const int64_t* __restrict__ row_map,
                                                        float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                        int32_t* __restrict__ out_count) {
-    __shared__ uint32_t hist[256];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[HIST_WORDS];
     __shared__ uint32_t bc[4];
     __shared__ float s_s[SELECT_MAX_K];
     __shared__ int64_t s_r[SELECT_MAX_K];

@@ -67,31 +67,42 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 
 // k-th largest key among the keys a block holds (1 <= k <= number of keys) by MSB-first 8-bit radix passes; all threads
 // of the block call it. `scan(f)` calls f(key) for every key THIS thread owns (from global memory, LDS or registers).
-// hist: 256 words of LDS, bc: 4 words of LDS. Returns the key; *n_gt = #keys strictly greater.
+// hist: HIST_WORDS words of LDS, bc: 4 words of LDS. Returns the key; *n_gt = #keys strictly greater.
+// The histogram is kept in HIST_COPIES interleaved copies, lane l adds to copy l % HIST_COPIES: the digits of a score row are
+// heavily skewed (the top byte of most keys is one of 3-5 values), and 64 lanes adding to one LDS address are served one
+// after the other; with 8 copies at most 8 queue on an address.
+constexpr int HIST_COPIES = 8;
+constexpr int HIST_WORDS = 256 * HIST_COPIES;
 template <class Scan>
 __device__ uint32_t block_kth_largest_scan(Scan scan, int64_t k, uint32_t* hist, uint32_t* bc, int64_t* n_gt) {
     uint32_t prefix = 0, pmask = 0;
     int64_t remaining = k, gt = 0;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    for (int i = threadIdx.x; i < HIST_WORDS; i += blockDim.x) hist[i] = 0;
     __syncthreads();
+    const uint32_t my_copy = threadIdx.x & (HIST_COPIES - 1);
     // two workgroup barriers per pass: wave 0 clears each bin right after reading it (the histogram is ready for the next
     // pass), and nobody overwrites bc[] before the next pass's first barrier
     for (int shift = 24; shift >= 0; shift -= 8) {
         // (measured and dropped: counting the skewed first digit with wave ballots instead of per-key atomics doubles the
         //  time of the four passes — the ballot / shuffle loop costs more than the queued LDS adds)
         scan([&](uint32_t key) {
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(((key >> shift) & 255u) << 3) | my_copy], 1u);
         });
         __syncthreads();
         // bin where the count taken from the top reaches `remaining`: wave 0, lane l owns bins 4l..4l+3, suffix sums by
         // shuffles, crossing lane by ballot (the counts are < 2^32 here; remaining <= n)
         if (threadIdx.x < 64) {
             const int l = threadIdx.x;
-            const uint32_t h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
-            hist[4 * l] = 0;
-            hist[4 * l + 1] = 0;
-            hist[4 * l + 2] = 0;
-            hist[4 * l + 3] = 0;
+            uint32_t hb[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {   // bins 4l..4l+3: sum their copies (two 16-byte reads each) and clear them for the next pass
+                uint4* cp = reinterpret_cast<uint4*>(hist + (4 * l + b) * HIST_COPIES);
+                const uint4 a = cp[0], c = cp[1];
+                hb[b] = a.x + a.y + a.z + a.w + c.x + c.y + c.z + c.w;
+                cp[0] = make_uint4(0, 0, 0, 0);
+                cp[1] = make_uint4(0, 0, 0, 0);
+            }
+            const uint32_t h0 = hb[0], h1 = hb[1], h2 = hb[2], h3 = hb[3];
             uint64_t suf = (uint64_t)h0 + h1 + h2 + h3;   // becomes sum over bins >= 4l
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {

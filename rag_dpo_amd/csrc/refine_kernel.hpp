@@ -75,7 +75,7 @@ __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand,
                                                 RefineCounters* __restrict__ ctr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2* list = reinterpret_cast<uint2*>(smem);                        // [REFINE_LIST]
-    __shared__ uint32_t hist[256];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[HIST_WORDS];
     __shared__ uint32_t bc[4];
     __shared__ uint32_t seg_off[REFINE_STREAMS + 1];
     __shared__ float s_s[REFINE_PMAX];

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 // Only the first n_sets_used sets (streams that scanned at least one tile) are looked at.
 __global__ __launch_bounds__(256) void k_tau(const float* __restrict__ setmax, int n_sets, int n_sets_used, int k,
                                              float two_e_scaled, int nq, float* __restrict__ tau) {
-    __shared__ uint32_t hist[256];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[HIST_WORDS];
     __shared__ uint32_t bc[4];
     const int q = blockIdx.x;
     if (q >= nq) {   // padding query (zero vector): must never emit
