@@ -62,6 +62,13 @@ namespace rdx {
 #define RDX_DMA_LATE_NUM 2  // late position = NG/2 + NUM*NG/8
 #endif
 
+#ifndef RDX_BAR_NUM
+#define RDX_BAR_NUM 4   // the per-step barrier sits in front of MFMA group RDX_BAR_NUM * NG / 8 (4 = mid-step). Measured at B = 1024, 10 M rows,
+                        // same box (barrier group / late-DMA group of 16): 8/12 (this) 1335-1343 TFLOP/s, 2/6 1291-1295, 0/4 1285, 4/6 1275-1280, 10/14 1250-1260
+#endif
+#ifndef RDX_PRIO
+#define RDX_PRIO 2   // which half of the workgroup runs at s_setprio 1: 0 none, 1 waves 4-7, 2 waves 0-3
+#endif
 #ifndef RDX_ZERO_C
 #define RDX_ZERO_C 0   // 1: the first MFMA of a tile takes C = 0 instead of a zeroed accumulator (un-tied destination: the register allocator then spills)
 #endif
@@ -451,8 +458,12 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     // while one wave of a SIMD sits in wait / barrier / DMA issue / emit check, the other one is in the middle
                     // of a pure MFMA stretch (MI355X_MICROARCH.md "Two waves per SIMD" item 9). The same counts hold for both
                     // halves: a late wave issued its pieces of image s+1 at the start of step s-2, 4 + V operations ago.
-                    const bool here = RDX_HALF_STAGGER ? (g == 0 ? dma_late : (g == NG / 2 ? !dma_late : false)) : g == NG / 2;
-                    if ((RDX_HALF_STAGGER && (g == 0 || g == NG / 2)) || (!RDX_HALF_STAGGER && g == NG / 2)) {
+                    constexpr int BAR_G = RDX_HALF_STAGGER ? NG / 2 : RDX_BAR_NUM * NG / 8;   // group in front of which the step's barrier sits
+                    // the counted wait below assumes that a wave's DMA issue and the barrier lie on the same side of the kk = 0 refill
+                    static_assert(RDX_HALF_STAGGER || !RDX_DMA_STAGGER || ((BAR_G < NG / 2) == (BAR_G + RDX_DMA_LATE_NUM * NG / 8 < NG / 2)), "barrier / late DMA position");
+                    static_assert(RDX_HALF_STAGGER || (BAR_G <= NG - PD && BAR_G + (RDX_DMA_STAGGER ? RDX_DMA_LATE_NUM * NG / 8 : 0) < NG), "barrier / late DMA position");
+                    const bool here = RDX_HALF_STAGGER ? (g == 0 ? dma_late : (g == NG / 2 ? !dma_late : false)) : g == BAR_G;
+                    if ((RDX_HALF_STAGGER && (g == 0 || g == NG / 2)) || (!RDX_HALF_STAGGER && g == BAR_G)) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (here) {
                             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + SIBN + V) : "memory");
@@ -465,7 +476,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     }
 #if !defined(RDX_ABL_NOB)
                     // (without the half-step stagger) the two waves of a SIMD issue their DMA pieces a quarter step apart
-                    if (!RDX_HALF_STAGGER && RDX_DMA_STAGGER && g == NG / 2 + RDX_DMA_LATE_NUM * NG / 8) {
+                    if (!RDX_HALF_STAGGER && RDX_DMA_STAGGER && g == BAR_G + RDX_DMA_LATE_NUM * NG / 8) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (dma_late) issue_b(ksb, (slot_c + 3) & 3);
                         __builtin_amdgcn_sched_barrier(0);
@@ -578,6 +589,10 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 
         // steps alternate between the two fragment register sets
         int s = 0;
+        // Static priority for one wave of every SIMD pair (MI355X_MICROARCH.md "Two waves per SIMD" item 4), set once, never
+        // flipped: waves 0-3 — the ones that refill the ring right behind the barrier. Same box, alternating, B = 1024 on 10 M
+        // rows: 1315 vs 1292-1308 TFLOP/s (+0.5 ... +1.6 %); the other half instead (RDX_PRIO 1): +0 ... +0.5 %; c3 unchanged.
+        if (RDX_PRIO != 0 && (RDX_PRIO == 1) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
         if constexpr (FUSED) {
             // Tile by tile (KS is even: every tile starts on the a0 register set). No branch ever chooses between two step
             // bodies (the register allocator answers that with a second copy of the accumulators): the first tile is peeled.
