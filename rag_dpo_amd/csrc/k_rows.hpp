@@ -232,6 +232,87 @@ __global__ __launch_bounds__(256) void k_exact_scores(MasterView master, int64_t
     }
 }
 
+// K5a for dim <= 1024 (U = float4 groups per lane, 1..4): the same scores, bit for bit, with three changes that matter at the
+// reference's own shape (16,919 rows, 4 queries, where this kernel IS the search). (1) The queries live in REGISTERS as
+// doubles (64 per lane at d = 1024) instead of being re-read from LDS and re-converted for every row: the grid is small enough
+// (2 blocks per CU) that a wave keeps them over ~8 rows. (2) The next row's loads are issued before the current row is
+// summed (two rows in flight per wave). (3) The four per-query butterflies run as ONE transposed butterfly: after the m = 32
+// stage a lane keeps two of the four partial sums, after m = 16 one, so 14 cross-lane dword moves and 7 additions replace 48
+// and 24 — every addition pairs the same two values as wave_sum's butterfly (lane order, oracle/rdx_oracle.c), so the bits
+// are the same. The sum of query j ends on lanes with (lane >> 4) == j.
+template <int U>
+__global__ __launch_bounds__(256, 2) void k_exact_scores_reg(MasterView master, int64_t rows, int dim,
+                                                             const float* __restrict__ qhat, const int32_t* __restrict__ q_list,
+                                                             int nq, const uint32_t* __restrict__ allow, float* __restrict__ out) {
+    const int n4 = dim >> 2;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    if (wave0 >= rows) return;
+    int gi[U];        // this lane's float4 groups (clamped: a group past the row's end re-reads the last one and counts as zeros)
+    bool gv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        gv[u] = lane + 64 * u < n4;
+        gi[u] = gv[u] ? lane + 64 * u : n4 - 1;
+    }
+    auto load_row = [&](int64_t r, float4 (&c)[U]) __attribute__((always_inline)) {
+        const MasterRow row4 = master_row(master, r, dim);
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = row4[gi[u]];
+    };
+    float4 cur[U], nxt[U];
+    load_row(wave0, cur);
+    double qd[QX][U][4];
+#pragma unroll
+    for (int j = 0; j < QX; ++j) {
+        const float4* src = reinterpret_cast<const float4*>(qhat + (int64_t)q_list[j < nq ? j : 0] * dim);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4 q = src[gi[u]];
+            const bool on = j < nq && gv[u];
+            qd[j][u][0] = on ? (double)q.x : 0.0;
+            qd[j][u][1] = on ? (double)q.y : 0.0;
+            qd[j][u][2] = on ? (double)q.z : 0.0;
+            qd[j][u][3] = on ? (double)q.w : 0.0;
+        }
+    }
+    const bool hi32 = (lane & 32) != 0, hi16 = (lane & 16) != 0;
+    for (int64_t r = wave0; r < rows; r += nwaves) {
+        const int64_t rn = r + nwaves < rows ? r + nwaves : r;   // (the last iteration re-reads its own row: no branch around loads)
+        load_row(rn, nxt);
+        const bool ok = !allow || ((allow[r >> 5] >> (r & 31)) & 1u);
+        double acc[QX];
+#pragma unroll
+        for (int j = 0; j < QX; ++j) acc[j] = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double cx = (double)cur[u].x, cy = (double)cur[u].y, cz = (double)cur[u].z, cw = (double)cur[u].w;
+#pragma unroll
+            for (int j = 0; j < QX; ++j) {
+                acc[j] += qd[j][u][0] * cx;   // (products of two floats are exact in double: fused or not, the same bits)
+                acc[j] += qd[j][u][1] * cy;
+                acc[j] += qd[j][u][2] * cz;
+                acc[j] += qd[j][u][3] * cw;
+            }
+        }
+        // transposed butterfly: m = 32 (keep queries {0,1} on lanes < 32, {2,3} on the others), m = 16, then m = 8..1 on the one left
+        const double s0 = hi32 ? acc[0] : acc[2], s1 = hi32 ? acc[1] : acc[3];   // what the partner keeps
+        double k0 = hi32 ? acc[2] : acc[0], k1 = hi32 ? acc[3] : acc[1];
+        k0 += __shfl_xor(s0, 32, 64);
+        k1 += __shfl_xor(s1, 32, 64);
+        const double s2 = hi16 ? k0 : k1;
+        double v = hi16 ? k1 : k0;
+        v += __shfl_xor(s2, 16, 64);
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        const int j = lane >> 4;
+        if ((lane & 15) == 0 && j < nq) out[(int64_t)j * rows + r] = ok ? (float)v : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+}
+
 // rank entries (score desc, row asc) held in LDS and write the best k; all threads of the block call it.
 // Wave-parallel: a wave takes entry i, its lanes take the entries j it is compared with (64 at a time), the rank is the
 // population count of the ballots — p/64 LDS reads per entry instead of p dependent ones per thread (p = 50: 5.2 -> ~1 us in

@@ -681,7 +681,18 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
     const int grid_rows = (int)std::min<int64_t>((h->rows + 3) / 4, (int64_t)h->n_cu * 16);   // one row per wave up to 16 Ki rows
     for (int j0 = 0; j0 < n_list; j0 += QX) {
         const int nq = std::min(QX, n_list - j0);
-        if (h->rows > 0) {
+        if (h->rows > 0 && h->dim <= 1024) {
+            // queries in registers, two rows in flight per wave, 2 blocks per CU (all resident at once)
+            const int u = (h->dim / 4 + 63) / 64;
+            const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((h->rows + 3) / 4, (int64_t)h->n_cu * 2))), b(256);
+#define RDX_K5A(U) hipLaunchKernelGGL(k_exact_scores_reg<U>, g, b, 0, st, h->mv(), h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>())
+            if (u == 1) RDX_K5A(1);
+            else if (u == 2) RDX_K5A(2);
+            else if (u == 3) RDX_K5A(3);
+            else RDX_K5A(4);
+#undef RDX_K5A
+            HIP_TRY(hipGetLastError());
+        } else if (h->rows > 0) {
             hipLaunchKernelGGL(k_exact_scores, dim3(std::max(grid_rows, 1)), dim3(256), (size_t)nq * h->dim * 4, st, h->mv(),
                                h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>());
             HIP_TRY(hipGetLastError());
@@ -824,7 +835,18 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         const int64_t want_rows = std::max<int64_t>(64 * (int64_t)k, 8192);
         int div = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(h->sample_div, h->rows / want_rows), 3000 / std::max(k, 1)));
         if (depth > 0) div = std::max(1, div / 8);   // second chance: 8x denser sample -> a threshold that sees the cluster
-        const int64_t n_sched = (n_tiles + div - 1) / div;
+        int64_t n_sched = (n_tiles + div - 1) / div;
+        // whole rounds only: the bootstrap takes as long as its busiest stream, so 77 tiles on 64 streams cost two tiles' time for
+        // 1.2 tiles' worth of threshold (a 1.25 M-row shard at B = 1024: 53 -> 27 us of a 2.26 ms search); thin the sample to the
+        // last full round instead, as long as it keeps the rows asked for above
+        if (n_sched > n_streams && n_sched % n_streams != 0) {
+            const int64_t full = n_sched / n_streams * n_streams;
+            const int div2 = (int)((n_tiles + full - 1) / full);
+            if ((n_tiles + div2 - 1) / div2 * 256 >= want_rows) {
+                div = div2;
+                n_sched = (n_tiles + div - 1) / div;
+            }
+        }
         sample_rows = n_sched * 256;
         const int n_sets_used = (int)std::min<int64_t>(n_streams, n_sched) * SETS_PER_STREAM;
         // slots per (query, stream) segment: 8x the expected hits, power of two, [32, 4096]
