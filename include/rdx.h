@@ -105,8 +105,9 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * and rdx_index_get need it — the operands and the operation of the ingest normalisation, hence the same bits. With the fp16
  * scan copy that is 4 instead of 6 B/element for a bf16 corpus (BASELINE config 5). Such an index takes rows through
  * rdx_index_add_bf16 only (rdx_index_add / _add_stored / _update return RDX_ERR_STATE);
- * "fuse_epilogue" 0/1 (default 0): B > 128 main scan variant whose per-tile emit check rides inside the
- * first k-step of the next tile instead of interrupting the MFMA stream (speed only; measured equal to 1 % slower);
+ * "fuse_epilogue" 0/1 (default 1): B > 128 main scan variant whose per-tile emit check rides inside the
+ * first k-step of the next tile instead of interrupting the MFMA stream (speed only: +1 % at B = 1024; used when the
+ * number of 64-element k-steps per row is even, the stand-alone check otherwise and with 0);
  * "retry" 0/1 (default 1): queries whose candidate
  * segments overflow get a second MFMA pass as a small batch (denser threshold sample) before the exact full scan. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);

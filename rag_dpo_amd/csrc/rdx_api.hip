@@ -131,7 +131,7 @@ struct rdx_index {
     std::mutex mu;
 
     // options
-    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 0, force_bn = 0;
+    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 1, force_bn = 0;
     double xw[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // relative speed of the XCDs as the last main scans showed it (sum 8)
     unsigned long long wg_times[1024] = {};    // start/end stamps of the last main scan's workgroups (host copy)
     int sample_div = 64;
@@ -654,8 +654,8 @@ static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, i
 #else
         constexpr bool HAVE_FUSED = true;
 #endif
-        // option fuse_epilogue (off: measured equal to -1 %): with an even number of k-steps per tile the emit
-        // check of a tile rides with the first k-step of the next one
+        // option fuse_epilogue (default on: +1 % at B = 1024 since the static wave priority went in): with an even
+        // number of k-steps per tile the emit check of a tile rides with the first k-step of the next one
         if constexpr (HAVE_FUSED) {
             if ((p.ksteps & 1) == 0 && h->fuse_epilogue) {
                 if (p.sib) return launch_scan<256, EPI, false, true, false, true>(h, p, grid, st);

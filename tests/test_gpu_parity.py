@@ -114,12 +114,14 @@ def test_search_in_two_halves(eng, oracle):
     ix.close()
 
 
-def test_fused_epilogue_variant(eng, oracle):
-    """option fuse_epilogue: the B > 128 main scan whose emit check rides in the next tile's first k-step — several tiles per
-    stream (so that the fused step runs), a ragged last tile, a row bitmap, planted near-duplicates, both against the oracle"""
+@pytest.mark.parametrize("fused", [1, 0])
+def test_fused_epilogue_variant(eng, oracle, fused):
+    """option fuse_epilogue (default 1): the B > 128 main scan whose emit check rides in the next tile's first k-step — several
+    tiles per stream (so that the fused step runs), a ragged last tile, a row bitmap, planted near-duplicates, against the
+    oracle; and the same with the option off (the stand-alone per-tile check, which odd k-step counts always take)"""
     corpus = synth.make_corpus(140_001, 256)           # 547 tiles over 64 streams: 8-9 tiles per stream; 4 k-steps per tile
     q = synth.make_queries(300, 256, corpus)
-    ix = _index(eng, corpus, force_fast=1, fuse_epilogue=1)
+    ix = _index(eng, corpus, force_fast=1, fuse_epilogue=fused)
     st = _check(oracle, ix, corpus, q, 10, expect_path=0)
     assert st["exact_queries"] == 0
     allow = np.random.default_rng(1).random(corpus.shape[0]) < 0.4

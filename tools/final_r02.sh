@@ -9,7 +9,7 @@ cd $R
 for w in c4 c3 c2 c1; do python3 bench.py --workload $w > $O/$w.json 2> $O/$w.err || echo "bench $w failed"; done
 python3 bench.py --workload c5 --no-cpu > $O/c5.json 2> $O/c5.err || echo "bench c5 failed"
 python3 bench.py --workload c5 --no-cpu --no-encode > $O/c5_noenc.json 2> /dev/null || echo "bench c5 noenc failed"
-python3 bench.py --workload c4 --no-cpu --set fuse_epilogue=1 > $O/c4_fused.json 2> /dev/null || echo "bench c4 fused failed"
+python3 bench.py --workload c4 --no-cpu --set fuse_epilogue=0 > $O/c4_unfused.json 2> /dev/null || echo "bench c4 unfused failed"
 python3 bench.py --workload c4 --no-cpu --set sib_sync=1 > $O/c4_sibsync.json 2> /dev/null || echo "bench c4 sib failed"
 bash tools/prof.sh r02 "--steps 5 --warmup 2 --no-cpu" || echo "prof failed $?"
 cd /tmp && export TMPDIR=/tmp
