@@ -59,7 +59,8 @@ namespace rdx {
 #define RDX_DMA_STAGGER 4   // wave-number mask: waves with (wave & mask) != 0 issue their query-image DMA later in the step
 #endif
 #ifndef RDX_DMA_LATE_NUM
-#define RDX_DMA_LATE_NUM 2  // late position = NG/2 + NUM*NG/8
+#define RDX_DMA_LATE_NUM 1  // late position = barrier group + NUM*NG/8. Round 1 chose 2 (a quarter step); with the fused emit check 1 is +0.2 ... +1 % on
+                            // every shape tried (c4, c3, a 1.25 M-row shard, B = 512), 3 is -6 %
 #endif
 
 #ifndef RDX_BAR_NUM
