@@ -59,8 +59,11 @@ namespace rdx {
 #define RDX_DMA_STAGGER 4   // wave-number mask: waves with (wave & mask) != 0 issue their query-image DMA later in the step
 #endif
 #ifndef RDX_DMA_LATE_NUM
-#define RDX_DMA_LATE_NUM 1  // late position = barrier group + NUM*NG/8. Round 1 chose 2 (a quarter step); with the fused emit check 1 is +0.2 ... +1 % on
-                            // every shape tried (c4, c3, a 1.25 M-row shard, B = 512), 3 is -6 %
+#define RDX_DMA_LATE_NUM 2  // late position = barrier group + NUM*NG/8 (a quarter step), for the variants with the stand-alone emit check
+#endif
+#ifndef RDX_DMA_LATE_NUM_FUSED
+#define RDX_DMA_LATE_NUM_FUSED 1  // ... and for the fused-check variants: an eighth of a step is +0.2 ... +1 % on every shape tried (c4, c3, a 1.25 M-row
+                                  // shard, B = 512), three eighths -6 %. (The stand-alone variants spill two to six registers with 1: they keep 2.)
 #endif
 
 #ifndef RDX_BAR_NUM
@@ -141,6 +144,7 @@ template <int BN, int EPI, bool HAS_MASK, bool RES, bool SIBT = false, bool NTT 
 __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     constexpr bool FUSED = FUSEDT && EPI == EPI_EMIT;
     constexpr bool NT_A = RDX_NT_SMALL && NTT;   // host: NTT launches have ONE query tile (every corpus byte is read by one workgroup)
+    constexpr int LATE_NUM = FUSED ? RDX_DMA_LATE_NUM_FUSED : RDX_DMA_LATE_NUM;   // where the late half issues its DMA (see `step`)
     constexpr int B_BYTES = BN * BK * 2;  // one k-step image of this workgroup's queries
     constexpr int NPB = BN / 64;          // 1 KiB DMA pieces per wave per query image
     // Sibling lock-step (speed only). The nqt workgroups of a stream read the same corpus tiles; nothing else keeps them
@@ -461,8 +465,8 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     // halves: a late wave issued its pieces of image s+1 at the start of step s-2, 4 + V operations ago.
                     constexpr int BAR_G = RDX_HALF_STAGGER ? NG / 2 : RDX_BAR_NUM * NG / 8;   // group in front of which the step's barrier sits
                     // the counted wait below assumes that a wave's DMA issue and the barrier lie on the same side of the kk = 0 refill
-                    static_assert(RDX_HALF_STAGGER || !RDX_DMA_STAGGER || ((BAR_G < NG / 2) == (BAR_G + RDX_DMA_LATE_NUM * NG / 8 < NG / 2)), "barrier / late DMA position");
-                    static_assert(RDX_HALF_STAGGER || (BAR_G <= NG - PD && BAR_G + (RDX_DMA_STAGGER ? RDX_DMA_LATE_NUM * NG / 8 : 0) < NG), "barrier / late DMA position");
+                    static_assert(RDX_HALF_STAGGER || !RDX_DMA_STAGGER || ((BAR_G < NG / 2) == (BAR_G + LATE_NUM * NG / 8 < NG / 2)), "barrier / late DMA position");
+                    static_assert(RDX_HALF_STAGGER || (BAR_G <= NG - PD && BAR_G + (RDX_DMA_STAGGER ? LATE_NUM * NG / 8 : 0) < NG), "barrier / late DMA position");
                     const bool here = RDX_HALF_STAGGER ? (g == 0 ? dma_late : (g == NG / 2 ? !dma_late : false)) : g == BAR_G;
                     if ((RDX_HALF_STAGGER && (g == 0 || g == NG / 2)) || (!RDX_HALF_STAGGER && g == BAR_G)) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     }
 #if !defined(RDX_ABL_NOB)
                     // (without the half-step stagger) the two waves of a SIMD issue their DMA pieces a quarter step apart
-                    if (!RDX_HALF_STAGGER && RDX_DMA_STAGGER && g == BAR_G + RDX_DMA_LATE_NUM * NG / 8) {
+                    if (!RDX_HALF_STAGGER && RDX_DMA_STAGGER && g == BAR_G + LATE_NUM * NG / 8) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (dma_late) issue_b(ksb, (slot_c + 3) & 3);
                         __builtin_amdgcn_sched_barrier(0);
