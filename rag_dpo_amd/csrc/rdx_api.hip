@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -1028,6 +1029,16 @@ static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stat
             }
             double dur[8], mean = 0;
             for (int x = 0; x < 8; ++x) mean += (dur[x] = (double)(tx[x] - t0)) / 8.0;
+            if (std::getenv("RDX_DEBUG_XCD")) {   // developer (tools/xcd_spread.py): when each XCD's last (first) workgroup ended, ms after the first start
+                std::fprintf(stderr, "xcd end ms:");
+                for (int x = 0; x < 8; ++x) {
+                    unsigned long long lo = ~0ull;
+                    for (int b = x; b < grid; b += 8)
+                        if ((b >> 3) < G * nqt) lo = std::min(lo, wt[2 * b + 1]);
+                    std::fprintf(stderr, " %.3f(%.3f)", dur[x] * 1e-5, (double)(lo - t0) * 1e-5);
+                }
+                std::fprintf(stderr, "\n");
+            }
             acc_stats->xcd_finish_spread_ms = (float)((*std::max_element(dur, dur + 8) - *std::min_element(dur, dur + 8)) * 1e-5);   // 100 MHz ticks
             acc_stats->xcd_share_min = (float)*std::min_element(h->xw, h->xw + 8);
             acc_stats->xcd_share_max = (float)*std::max_element(h->xw, h->xw + 8);
