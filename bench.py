@@ -269,7 +269,7 @@ def main():
     if encode:
         from rag_dpo_amd.embedding_provider import EmbeddingProvider
         provider = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device=str(device), dtype=torch.float16,
-                                     batch_size=int(os.environ.get("RDX_ENC_BATCH", "512"))).load()
+                                     batch_size=int(os.environ.get("RDX_ENC_BATCH", "1024"))).load()
         texts = synth.query_texts(B)
 
     def step():
@@ -290,31 +290,13 @@ def main():
     exact_ms = 0.0
     serial = None
     if encode and not args.no_overlap:
-        # C5 step = encode B texts + search. The two are pipelined: a worker thread runs the search of batch i on its own
-        # stream (rdx_search blocks only that thread: ctypes releases the GIL and the library waits on its mailbox) while
-        # the main thread encodes batch i+1 on another stream. Both phases are compute-bound on the same CUs, so what the
-        # overlap hides is each phase's idle tail and launch gaps, not the phases themselves; K steps are still K encodes +
-        # K searches inside the timed region. A short serial leg (encode, then search, one stream) is reported beside it.
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=1)
-        s_enc, s_srch = torch.cuda.Stream(device), torch.cuda.Stream(device)
-
-        def encode_on_stream():
-            with torch.cuda.stream(s_enc):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                q = provider.embed_device(texts)
-                e1.record()
-                enc_ev.append((e0, e1))
-            q.record_stream(s_srch)
-            return q, e1
-
-        def search_on_stream(q, ready):
-            with torch.cuda.stream(s_srch):
-                s_srch.wait_event(ready)
-                out_ = searcher.search(q, k)
-                return out_, shard.index.last_stats()
-
+        # C5 step = encode B texts + search, software-pipelined on ONE stream: the search of batch i is enqueued
+        # (search_begin), the encode of batch i+1 — tokenising on the host, then the forward's launches — is issued behind it
+        # on the same stream, and only then does the host wait for the search (search_end). Both phases are compute-bound on
+        # the same CUs, so they do not run beside each other on the GPU (an earlier version on two streams with a worker thread
+        # measured SLOWER than the serial order once the tokeniser stopped being the slow part); what the pipeline hides is
+        # the host's share of the encode (tokenise + ~500 launches) behind the 16 ms scan. K steps are still K encodes + K
+        # searches inside the timed region. A short serial leg (encode, wait, search, wait) is reported beside it.
         n_serial = max(2, min(5, args.steps))
         t0s = time.perf_counter()
         for _ in range(n_serial):
@@ -325,19 +307,29 @@ def main():
         enc_ev.clear()
         barrier()
         t0 = time.perf_counter()
-        q_next, ready = encode_on_stream()
+
+        def encode_now():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            q_ = provider.embed_device(texts)
+            e1.record()
+            enc_ev.append((e0, e1))
+            return q_
+
+        q_next = encode_now()
         for i in range(args.steps):
-            fut = pool.submit(search_on_stream, q_next, ready)
+            q_cur = q_next
+            searcher.search_begin(q_cur, k)
             if i + 1 < args.steps:
-                q_next, ready = encode_on_stream()
-            _, st = fut.result()
+                q_next = encode_now()
+            searcher.search_end()
+            st = shard.index.last_stats()
             scan_ms += st["ms_scan_main"]
             exact_ms += st["ms_exact"]
             tot_ms += st["ms_total"]
             stats = st
         barrier()
         elapsed = time.perf_counter() - t0
-        pool.shutdown()
     else:
         t0 = time.perf_counter()
         for _ in range(args.steps):

@@ -106,8 +106,17 @@ class ShardedSearcher:
         query_src = r: only rank r's `queries` holds the batch (the rank that took the request); the other ranks pass a
         tensor of the same shape to receive it — one broadcast (B*d*4 bytes: 4 MB at B = 1024) in front of the scan
         (SURVEY.md §8e)."""
+        self.search_begin(queries, k, query_src)
+        return self.search_end()
+
+    def search_begin(self, queries: torch.Tensor, k: int, query_src: Optional[int] = None) -> None:
+        """everything of search() that is ENQUEUED: the shard's search, the exchange step and the merge go onto the current
+        stream and the call returns; search_end() waits and hands out the result. Work the caller enqueues on the same stream in
+        between (the encode of its next query batch, BASELINE config 5) runs right behind the search without waiting for the host."""
         if k < 1:
             raise ValueError("k must be >= 1")
+        if getattr(self, "_open", None) is not None:
+            raise RuntimeError("search_begin() twice without search_end()")
         nq = queries.shape[0]
         if query_src is not None and self.world > 1:
             if self.host_staged:
@@ -124,29 +133,35 @@ class ShardedSearcher:
         deferred = hasattr(self.shard, "search_async") and self.shard.search_async(queries, k, s, r, c)
         if not deferred:
             self.shard.search(queries, k, s, r, c)
-        if self.world == 1 and not (self.always_exchange and dist.is_initialized()):
-            if deferred:
-                self.shard.search_wait()
-            return s, r, c
+        exchange = not (self.world == 1 and not (self.always_exchange and dist.is_initialized()))
+        if exchange:
+            self._exchange(nq, k)
+        self._open = (nq, k, deferred, exchange)
+
+    def _exchange(self, nq: int, k: int) -> None:
+        per_pad, local, allb, out = self._buffers(nq, k)
         if self.host_staged:
             # rehearsal only (several ranks sharing ONE GPU over gloo, which cannot move device memory): same packed
             # layout, same merge kernel, the collective alone goes through host memory
-            h_local = local.cpu()
             h_all = torch.empty(self.world * per_pad, dtype=torch.uint8)
-            dist.all_gather_into_tensor(h_all, h_local, group=self.group)
+            dist.all_gather_into_tensor(h_all, local.cpu(), group=self.group)
             allb.copy_(h_all)
         else:
             dist.all_gather_into_tensor(allb, local, group=self.group)   # the ONE exchange step (RCCL over xGMI)
         self.shard.merge_packed(allb, per_pad, self.world, nq, k, out[0], out[1], out[2])
+
+    def search_end(self):
+        if getattr(self, "_open", None) is None:
+            raise RuntimeError("search_end() without search_begin()")
+        nq, k, deferred, exchange = self._open
+        self._open = None
+        per_pad, local, allb, out = self._buffers(nq, k)
+        if not exchange:
+            if deferred:
+                self.shard.search_wait()
+            return self.views(local, nq, k)
         if deferred and self._any_redone(self.shard.search_wait()):
-            # some rank's fallback passes rewrote its partial after the first exchange: exchange and merge again
-            if self.host_staged:
-                h_all = torch.empty(self.world * per_pad, dtype=torch.uint8)
-                dist.all_gather_into_tensor(h_all, local.cpu(), group=self.group)
-                allb.copy_(h_all)
-            else:
-                dist.all_gather_into_tensor(allb, local, group=self.group)
-            self.shard.merge_packed(allb, per_pad, self.world, nq, k, out[0], out[1], out[2])
+            self._exchange(nq, k)   # some rank's fallback passes rewrote its partial after the first exchange: exchange and merge again
         return out
 
     def _any_redone(self, mine: bool) -> bool:
