@@ -91,6 +91,19 @@ def _worker(rank, world, port, n, dim, b, k, out_dir):
     s, r, c = s.clone(), r.clone(), c.clone()
     s2, r2, c2 = ss.search(q, k)                                    # replicated batch, no broadcast
     assert torch.equal(r, r2) and torch.equal(s, s2) and torch.equal(c, c2)
+    ss.search_begin(q, k)                                           # the two halves (other work may be enqueued in between)
+    try:
+        ss.search_begin(q, k)
+        raise AssertionError("second search_begin() accepted")
+    except RuntimeError:
+        pass
+    s4, r4, c4 = ss.search_end()
+    assert torch.equal(r, r4) and torch.equal(s, s4) and torch.equal(c, c4)
+    try:
+        ss.search_end()
+        raise AssertionError("search_end() without search_begin() accepted")
+    except RuntimeError:
+        pass
     # asynchronous form: rank 1's first pass is incomplete for queries 2 and 5 (every other rank's is complete) — all ranks
     # must repeat the exchange and end with the same, complete result; with nothing late nobody repeats it
     for late in ([2, 5], []):
