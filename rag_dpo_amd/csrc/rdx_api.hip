@@ -927,6 +927,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             // LDS list of the gathered hits: 16x the expected count (heavy-tailed score distributions of structured corpora; a list overflow costs a second pass), at most REFINE_LIST
             uint32_t list_cap = 1024;
             while (list_cap < (uint32_t)REFINE_LIST && list_cap < 16.0 * exp_hits * n_streams) list_cap *= 2;
+            list_cap = std::min<uint32_t>(list_cap, REFINE_LIST);
             const size_t lds = (size_t)list_cap * 8;
             RDX_TRY(ensure_dynamic_lds(h, (const void*)k_refine, lds));
             hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(1024), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,

@@ -6,7 +6,8 @@
 namespace rdx {
 
 constexpr int REFINE_PMAX = 1024;    // most candidates re-scored exactly per query; more -> exact full scan
-constexpr int REFINE_LIST = 8192;    // most scan hits gathered per query (64 KiB of LDS); more -> exact full scan
+constexpr int REFINE_LIST = 7168;    // most scan hits gathered per query (56 KiB of LDS: with the 22 KiB of static LDS TWO blocks fit a CU's 160 KiB —
+                                     // at B = 1024 the kernel runs in two rounds instead of four); more -> second pass / exact full scan
 constexpr int REFINE_STREAMS = 512;  // most (query, stream) segments
 
 struct RefineCounters {   // one per index, zeroed before every search
