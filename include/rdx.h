@@ -93,7 +93,9 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
 
 /* Options (tests and benchmarks): "force_exact" 0/1, "force_fast" 0/1 (MFMA scan even for small
  * problems), "sample_div" >=1, "cand_cap" 0 (auto) or slots per (query, stream) candidate segment,
- * "profile" 0/1 (record HIP events around every kernel of the next searches); "row_base" >= 0:
+ * "profile" 0..3: 1 = HIP events around every kernel of the next searches, 2 = two events around the dominant kernel(s) only
+ * (main scan, or K5a + K5b on the exact path), 3 = no events: those kernels stamp their own first-workgroup start and
+ * last-workgroup end (an event record costs the stream ~6 us, 10 % of a small search) — rdx_search_stats.ms_*; "row_base" >= 0:
  * added to every returned row id, so a shard holding rows [base, base+count) answers with GLOBAL ids;
  * "sib_sync" 0/1 (default 0) and "sib_lag" 3..100 (k-steps): soft lock-step of the workgroups that stream
  * the same corpus tiles for different query tiles (less fabric traffic for ~2-3 % of the throughput while the

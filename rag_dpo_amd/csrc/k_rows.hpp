@@ -179,8 +179,9 @@ constexpr int QX = 4;
 __global__ __launch_bounds__(256) void k_exact_scores(MasterView master, int64_t rows, int dim,
                                                       const float* __restrict__ qhat, const int32_t* __restrict__ q_list,
                                                       int nq, const uint32_t* __restrict__ allow,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, unsigned long long* __restrict__ t_first_inv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (t_first_inv && threadIdx.x == 0) atomicMax(t_first_inv, ~wall_clock64());   // profile = 3: earliest block start
     float4* q4 = reinterpret_cast<float4*>(smem);   // [nq][dim/4]
     const int n4 = dim >> 2;
     for (int j = 0; j < nq; ++j) {
@@ -243,7 +244,9 @@ __global__ __launch_bounds__(256) void k_exact_scores(MasterView master, int64_t
 template <int U>
 __global__ __launch_bounds__(256, 2) void k_exact_scores_reg(MasterView master, int64_t rows, int dim,
                                                              const float* __restrict__ qhat, const int32_t* __restrict__ q_list,
-                                                             int nq, const uint32_t* __restrict__ allow, float* __restrict__ out) {
+                                                             int nq, const uint32_t* __restrict__ allow, float* __restrict__ out,
+                                                             unsigned long long* __restrict__ t_first_inv) {
+    if (t_first_inv && threadIdx.x == 0) atomicMax(t_first_inv, ~wall_clock64());   // profile = 3: earliest block start
     const int n4 = dim >> 2;
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
                                                        const int32_t* __restrict__ q_list, int k, int64_t row_base,
                                                        const int64_t* __restrict__ row_map,
                                                        float* __restrict__ out_score, int64_t* __restrict__ out_row,
-                                                       int32_t* __restrict__ out_count) {
+                                                       int32_t* __restrict__ out_count, unsigned long long* __restrict__ t_last) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[HIST_WORDS];
     __shared__ uint32_t bc[4];
     __shared__ float s_s[SELECT_MAX_K];
@@ -496,6 +499,10 @@ __global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__
     const int valid = n_fin;
     RDX_STAMP(5);
     rank_and_write(s_s, s_r, p, valid < k ? valid : k, o_s, o_r, out_count + q);
+    if (t_last) {   // profile = 3: latest block end
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(t_last, wall_clock64());
+    }
     RDX_STAMP(6);
     // rank_and_write filled [valid, k) only up to its own k argument; pad the rest
     for (int i = valid + threadIdx.x; i < k; i += blockDim.x) {

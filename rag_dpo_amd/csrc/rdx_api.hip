@@ -365,7 +365,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
         for (double& w : h->xw) w = 1.0;
     }
     else if (n == "sib_lag") h->sib_lag = (int)std::min<int64_t>(std::max<int64_t>(value, 3), 100);
-    else if (n == "profile") h->profile = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
+    else if (n == "profile") h->profile = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 3);
     else if (n == "sample_div") {
         if (value < 1) return fail(RDX_ERR_INVALID, "sample_div must be >= 1");
         h->sample_div = (int)std::min<int64_t>(value, 1 << 20);
@@ -677,7 +677,10 @@ static const int K_FAST_MAX = 256;   // larger k goes through the exact full sca
 
 // exact full scan for the queries listed in d_list[0..n_list)
 static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, const uint32_t* d_allow, float* d_score,
-                     int64_t* d_row, int32_t* d_count, hipStream_t st) {
+                     int64_t* d_row, int32_t* d_count, hipStream_t st, bool stamps = false) {
+    // profile = 3: the scoring kernel's first block and the select kernel's last block leave their times in the counter block
+    unsigned long long* t_first = stamps ? reinterpret_cast<unsigned long long*>(h->ctr.as<char>() + offsetof(RefineCounters, t_first_inv)) : nullptr;
+    unsigned long long* t_last = stamps ? reinterpret_cast<unsigned long long*>(h->ctr.as<char>() + offsetof(RefineCounters, t_last)) : nullptr;
     RDX_TRY(h->dense.ensure((size_t)QX * std::max<int64_t>(h->rows, 1) * 4));
     const int grid_rows = (int)std::min<int64_t>((h->rows + 3) / 4, (int64_t)h->n_cu * 16);   // one row per wave up to 16 Ki rows
     for (int j0 = 0; j0 < n_list; j0 += QX) {
@@ -686,7 +689,7 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
             // queries in registers, two rows in flight per wave, 2 blocks per CU (all resident at once)
             const int u = (h->dim / 4 + 63) / 64;
             const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((h->rows + 3) / 4, (int64_t)h->n_cu * 2))), b(256);
-#define RDX_K5A(U) hipLaunchKernelGGL(k_exact_scores_reg<U>, g, b, 0, st, h->mv(), h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>())
+#define RDX_K5A(U) hipLaunchKernelGGL(k_exact_scores_reg<U>, g, b, 0, st, h->mv(), h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>(), t_first)
             if (u == 1) RDX_K5A(1);
             else if (u == 2) RDX_K5A(2);
             else if (u == 3) RDX_K5A(3);
@@ -695,11 +698,11 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
             HIP_TRY(hipGetLastError());
         } else if (h->rows > 0) {
             hipLaunchKernelGGL(k_exact_scores, dim3(std::max(grid_rows, 1)), dim3(256), (size_t)nq * h->dim * 4, st, h->mv(),
-                               h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>());
+                               h->rows, h->dim, h->qhat.as<float>(), d_list + j0, nq, d_allow, h->dense.as<float>(), t_first);
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_select_dense, dim3(nq), dim3(1024), 0, st, h->dense.as<float>(), h->rows, d_list + j0, k, h->row_base,
-                           h->row_map, d_score, d_row, d_count);
+                           h->row_map, d_score, d_row, d_count, t_last);
         HIP_TRY(hipGetLastError());
     }
     return RDX_OK;
@@ -769,7 +772,8 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
                         int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth = 0,
                         HostOut* ho = nullptr, bool defer = false) {
     const int nq_pad = (int)((nq + 255) / 256 * 256);
-    const bool prof_all = h->profile == 1 && depth == 0, prof_main = h->profile != 0 && depth == 0;
+    const bool prof_all = h->profile == 1 && depth == 0, prof_main = (h->profile == 1 || h->profile == 2) && depth == 0;
+    const bool prof_stamps = h->profile == 3 && depth == 0;   // the kernels stamp their own times: nothing extra on the stream
     auto mark = [&](int i) {
         if (prof_all || (prof_main && (i == 3 || i == 4))) (void)hipEventRecord(h->ev[i], st);
     };
@@ -812,7 +816,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             HIP_TRY(hipMemcpyAsync(h->iota.p, io.data(), cnt * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
-        RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st));
+        RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st, prof_stamps));
         for (int i = 4; i <= 5; ++i) mark(i);
     } else {
         // queries per workgroup: 64 (tile resident in LDS), 128, 256. 257..384 queries run as three 128-query tiles rather than
@@ -919,6 +923,10 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             }
             p.xlo[8] = (int)n_tiles;
         }
+        if (prof_stamps && !balance) {
+            RDX_TRY(h->wgt.ensure((size_t)grid * 16));
+            p.wgt = h->wgt.as<unsigned long long>();
+        }
         RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, res, p, grid, st));
         p.use_xlo = 0;
         p.wgt = nullptr;
@@ -949,7 +957,8 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         HIP_TRY(hipMemcpyAsync(ho->count, d_count, b_c, hipMemcpyDeviceToHost, st));
     }
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, st, h->ctr.as<RefineCounters>(), h->mbox_dev, seq,
-                       balance ? h->wgt.as<unsigned long long>() : (const unsigned long long*)nullptr, balance ? 2 * grid : 0,
+                       (balance || (prof_stamps && !exact_only)) ? h->wgt.as<unsigned long long>() : (const unsigned long long*)nullptr,
+                       (balance || (prof_stamps && !exact_only)) ? 2 * grid : 0,
                        reinterpret_cast<const uint32_t*>(d_row), reinterpret_cast<uint32_t*>(h->pin_out_dev), (int64_t)(ride ? b_r / 4 : 0),
                        reinterpret_cast<const uint32_t*>(d_score), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r), (int64_t)(ride ? b_s / 4 : 0),
                        reinterpret_cast<const uint32_t*>(d_count), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r + b_s), (int64_t)(ride ? b_c / 4 : 0));
@@ -998,7 +1007,8 @@ static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stat
     const bool exact_only = ps.exact_only, balance = ps.balance, ride = ps.ride;
     const int64_t sample_rows = ps.sample_rows;
     const size_t b_s = ps.b_s, b_r = ps.b_r, b_c = ps.b_c;
-    const bool prof_all = h->profile == 1 && depth == 0, prof_main = h->profile != 0 && depth == 0;
+    const bool prof_all = h->profile == 1 && depth == 0, prof_main = (h->profile == 1 || h->profile == 2) && depth == 0;
+    const bool prof_stamps = h->profile == 3 && depth == 0;   // the kernels stamp their own times: nothing extra on the stream
     auto mark = [&](int i) {
         if (prof_all || (prof_main && (i == 3 || i == 4))) (void)hipEventRecord(h->ev[i], st);
     };
@@ -1114,6 +1124,20 @@ static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stat
         acc_stats->profiled = 2;
         if (exact_only) acc_stats->ms_exact += ms;   // exact path: K5a + K5b
         else acc_stats->ms_scan_main += ms;
+    } else if (prof_stamps) {
+        // first workgroup start -> last workgroup end of the dominant kernel(s), from the kernels' own 100 MHz stamps
+        acc_stats->profiled = 3;
+        if (exact_only) {
+            if (mb.t_last > mb.t_first) acc_stats->ms_exact += (float)((double)(mb.t_last - mb.t_first) * 1e-5);
+        } else {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int b = 0; b < grid; ++b) {
+                if ((b >> 3) >= G * nqt) continue;   // idle workgroups return before they stamp
+                t0 = std::min(t0, mb.wg_times[2 * b]);
+                t1 = std::max(t1, mb.wg_times[2 * b + 1]);
+            }
+            if (t1 > t0) acc_stats->ms_scan_main += (float)((double)(t1 - t0) * 1e-5);
+        }
     }
     return RDX_OK;
 }

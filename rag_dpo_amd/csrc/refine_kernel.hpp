@@ -17,6 +17,9 @@ struct RefineCounters {   // one per index, zeroed before every search
     int bad;              // set by K1 when a query embedding holds NaN/Inf
     int oob;              // RDX_CHECK_BOUNDS builds: the scan computed a corpus address outside the scan copy
     int pad0;
+    // option profile = 3 (kernels stamp their own times, no HIP events on the stream): when the first block of the exact path's
+    // scoring kernel started (kept as max(~clock): zero = unset) and when the last block of its select kernel ended (100 MHz ticks)
+    unsigned long long t_first_inv, t_last;
 };
 
 // What the LAST kernel of a search leaves in pinned host memory (written straight over PCIe, no memcpy, no interrupt):
@@ -26,6 +29,7 @@ struct Mailbox {
     unsigned long long emitted, rescored;
     int n_exact, bad;
     int oob, pad0;
+    unsigned long long t_first, t_last;   // profile = 3, exact path (see RefineCounters)
     unsigned long long wg_times[1024]; // [grid][2] start/end stamps of the main scan's workgroups (XCD balancing)
 };
 
@@ -50,6 +54,10 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
         mb->n_exact = ctr->n_exact;
         mb->bad = ctr->bad;
         mb->oob = ctr->oob;
+        mb->t_first = ~ctr->t_first_inv;
+        mb->t_last = ctr->t_last;
+        ctr->t_first_inv = 0;
+        ctr->t_last = 0;
         ctr->oob = 0;
         ctr->emitted = 0;
         ctr->rescored = 0;
