@@ -60,6 +60,26 @@ def test_exact_path_small(eng, oracle):
     _check(oracle, ix, corpus, q[:1], 50, expect_path=1)   # the reference's production shape: B=1, k=50
 
 
+@pytest.mark.parametrize("d", [64, 200, 320, 700, 1024, 1280, 2048])
+def test_exact_scores_and_rescore_every_width(eng, oracle, d):
+    """K5a keeps the queries in registers for dim <= 1024 (one to four float4 groups per lane, the last one partly empty when dim is
+    not a multiple of 256) and falls back to the LDS form above; K4's re-score has the same split. Both paths, six queries (a full
+    and a partial group of four), with and without a row bitmap."""
+    corpus = synth.make_corpus(3000, d)
+    q = synth.make_queries(6, d, corpus)
+    ix = _index(eng, corpus)
+    st = _check(oracle, ix, corpus, q, 20, expect_path=1)
+    assert st["exact_queries"] == 6
+    allow = np.random.default_rng(d).random(corpus.shape[0]) < 0.3
+    _check(oracle, ix, corpus, q, 20, allow, expect_path=1)
+    ix.close()
+    corpus = synth.make_corpus(30_000, d)
+    q = synth.make_queries(70, d, corpus)
+    ix = _index(eng, corpus, force_fast=1)
+    _check(oracle, ix, corpus, q, 30, expect_path=0)
+    ix.close()
+
+
 @pytest.mark.parametrize("n,b,k", [(20000, 64, 10), (16919, 4, 50), (30011, 130, 10), (25000, 257, 100)])
 def test_fast_path_parity(eng, oracle, n, b, k):
     corpus = synth.make_corpus(n, 1024)
