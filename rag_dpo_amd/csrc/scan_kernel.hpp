@@ -389,6 +389,16 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 
         int it = 0, ks = 0;                  // step being computed
         int it2 = AD / KS, ks2 = AD % KS;    // step s+AD (corpus fragments prefetched during step s)
+        // its address, kept as a running pointer: + 4096 per k-step, recomputed (three 64-bit multiplies) once per tile instead
+        // of in every step — the listing showed ~45 scalar instructions of address arithmetic in each half of a k-step
+        // (the bootstrap variants, with their 16 running maxima, spill two registers with it and keep the recomputation)
+#ifdef RDX_CHECK_BOUNDS
+        constexpr bool RUNNING_A = false;   // (every address the test build computes goes through the checking helper and must be a real one)
+#else
+        constexpr bool RUNNING_A = EPI == EPI_EMIT;
+#endif
+        const char* a_next = RUNNING_A ? a_src(it2, ks2) : nullptr;
+        const char* const a_first = RUNNING_A ? a_src(0, 0) : nullptr;   // what a step beyond the stream's end re-reads (never consumed)
         int slot_c = 0;                // ring slot of step s (= s mod 4)
         int ksb = 3 % KS;              // k-step image that step s+3 reads (issued during step s)
 
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
             const char* st = smem + (RES ? ks : slot_c) * B_BYTES;
             const char* stn = smem + (RES ? ksn : ((slot_c + 1) & 3)) * B_BYTES;   // image of step s+1
             const bool more = s + AD < total;   // step s+AD exists; otherwise re-read this stream's first step (never used)
-            const char* an = a_src(more ? it2 : 0, more ? ks2 : 0);
+            const char* an = RUNNING_A ? (more ? a_next : a_first) : a_src(more ? it2 : 0, more ? ks2 : 0);
             float tq_cur = 0.f;   // FUSE: this lane's threshold for the next block to check, fetched one block ahead
             int tb = l15 * NB16;
             if constexpr (FUSE) {
@@ -590,7 +600,13 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
             const bool last_k = ks == KS - 1;
             const int it_done = it;
             if (++ks == KS) { ks = 0; ++it; }
-            if (++ks2 == KS) { ks2 = 0; ++it2; }
+            if (++ks2 == KS) {
+                ks2 = 0;
+                ++it2;
+                if constexpr (RUNNING_A) a_next = a_src(it2, 0);   // (beyond the stream's last tile: an address nobody loads from)
+            } else {
+                if constexpr (RUNNING_A) a_next += 4096;
+            }
             slot_c = (slot_c + 1) & 3;
             if (++ksb == KS) ksb = 0;
             if constexpr (!FUSED) {
