@@ -46,7 +46,10 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
     for (int64_t i = threadIdx.x; i < w1; i += blockDim.x) d1[i] = s1[i];
     for (int64_t i = threadIdx.x; i < w2; i += blockDim.x) d2[i] = s2[i];
     for (int i = threadIdx.x; i < n_wgt; i += blockDim.x) mb->wg_times[i] = wgt[i];
-    __threadfence_system();
+    // every storing wave waits for its own stores, the barrier collects the waves, and ONE lane makes the block's stores visible to
+    // the host (system-scope release) before it publishes the sequence number — not a system-scope fence in all 1024 threads
+    // (MI355X_MICROARCH.md, inter-workgroup visibility: "every storing wave's s_waitcnt vmcnt(0) -> __syncthreads() -> lane-0 fence")
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         mb->emitted = ctr->emitted;
@@ -63,8 +66,9 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
         ctr->rescored = 0;
         ctr->n_exact = 0;
         ctr->bad = 0;
-        __threadfence_system();
-        __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the block's stores (L2 written back) before the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (always, behind a release fence: the compiler may drop its own wait)
+        __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
