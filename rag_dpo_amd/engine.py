@@ -200,6 +200,12 @@ class HipIndex:
         L.check(self._lib.rdx_search_wait(self._h, ctypes.byref(redone)))
         return bool(redone.value)
 
+    def last_stats_struct(self):
+        """the raw rdx_search_stats of the last search (a ctypes struct: field access without building a dict)"""
+        s = L.SearchStats()
+        L.check(self._lib.rdx_search_last_stats(self._h, ctypes.byref(s)))
+        return s
+
     def last_stats(self) -> dict:
         s = L.SearchStats()
         L.check(self._lib.rdx_search_last_stats(self._h, ctypes.byref(s)))
