@@ -85,13 +85,34 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
         }
         return reinterpret_cast<const float4*>(in + i * (int64_t)dim)[g];
     };
+    // dim <= 1024: the row's (up to) four float4 groups per lane are requested together and kept in registers for the second
+    // pass — one memory round trip instead of four dependent ones plus four re-reads (a query batch is a handful of rows: the
+    // kernel is all latency). Same additions in the same order per lane, same butterfly: the same bits.
+    const bool in_regs = n4 <= 256;
+    float4 rv[4];
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rv[u] = load4(lane + 64 * u < n4 ? lane + 64 * u : n4 - 1);
+    }
     double acc = 0.0;
-    for (int g = lane; g < n4; g += 64) {
-        const float4 v = load4(g);
-        acc += (double)v.x * (double)v.x;
-        acc += (double)v.y * (double)v.y;
-        acc += (double)v.z * (double)v.z;
-        acc += (double)v.w * (double)v.w;
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (lane + 64 * u < n4) {
+                acc += (double)rv[u].x * (double)rv[u].x;
+                acc += (double)rv[u].y * (double)rv[u].y;
+                acc += (double)rv[u].z * (double)rv[u].z;
+                acc += (double)rv[u].w * (double)rv[u].w;
+            }
+        }
+    } else {
+        for (int g = lane; g < n4; g += 64) {
+            const float4 v = load4(g);
+            acc += (double)v.x * (double)v.x;
+            acc += (double)v.y * (double)v.y;
+            acc += (double)v.z * (double)v.z;
+            acc += (double)v.w * (double)v.w;
+        }
     }
     const double n2 = wave_sum(acc);
     if (!(n2 < 1.0e300)) {   // NaN or Inf somewhere in the row: reject the whole call
@@ -103,8 +124,7 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
     if (verbatim) den = 1.0;   // rows that ARE stored values (snapshot reload): x / 1.0 == x, kept bit for bit
     const int64_t dst = dst_rows ? dst_rows[i] : row0 + i;
     if (master.raw16 && lane == 0) master.den[dst] = den;   // compact master: the raw row + its divisor
-    for (int g = lane; g < n4; g += 64) {
-        const float4 v = load4(g);
+    auto emit = [&](int g, const float4& v) __attribute__((always_inline)) {
         float4 y;
         y.x = (float)((double)v.x / den);
         y.y = (float)((double)v.y / den);
@@ -113,6 +133,13 @@ __global__ __launch_bounds__(256) void k_normalize(const float* __restrict__ in,
         if (master.f32) reinterpret_cast<float4*>(master.f32 + dst * (int64_t)dim)[g] = y;
         if (master.raw16) reinterpret_cast<ushort4*>(master.raw16 + dst * (int64_t)dim)[g] = reinterpret_cast<const ushort4*>(in_bf16 + i * (int64_t)dim)[g];
         if (shadow) shadow_store4<QUERY>(shadow, dst, 4 * g, ksteps, scale, y);
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lane + 64 * u < n4) emit(lane + 64 * u, rv[u]);
+    } else {
+        for (int g = lane; g < n4; g += 64) emit(g, load4(g));
     }
 }
 
