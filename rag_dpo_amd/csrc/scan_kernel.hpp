@@ -715,7 +715,34 @@ __global__ __launch_bounds__(256) void k_tau(const float* __restrict__ setmax, i
         return;
     }
     int64_t n_gt;
-    const uint32_t key = block_kth_largest([&](int64_t i) { return f2key(sm[i]); }, n_sets_used, k, hist, bc, &n_gt);
+    uint32_t key;
+    // Every radix pass used to re-read the maxima from global memory, one dependent load per key and thread: they are loaded once,
+    // all loads in flight (clamped index, value masked afterwards: a guarded load becomes a branch per load), RN keys per thread
+    // (256 threads; 8 for up to 2048 maxima, 32 for up to 8192; more are re-read per pass as before).
+    auto in_regs = [&](auto rn_tag) __attribute__((always_inline)) {
+        constexpr int RN = decltype(rn_tag)::value;
+        float vreg[RN];
+        uint32_t kreg[RN];
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int i = j * 256 + (int)threadIdx.x;
+            vreg[j] = sm[i < n_sets_used ? i : n_sets_used - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < RN; ++j) asm volatile("" : "+v"(vreg[j]));
+#pragma unroll
+        for (int j = 0; j < RN; ++j) kreg[j] = f2key(vreg[j]);
+        return block_kth_largest_scan(
+            [&](auto f) {
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    if (j * 256 + (int)threadIdx.x < n_sets_used) f(kreg[j]);
+            },
+            k, hist, bc, &n_gt);
+    };
+    if (n_sets_used <= 8 * 256) key = in_regs(std::integral_constant<int, 8>{});
+    else if (n_sets_used <= 32 * 256) key = in_regs(std::integral_constant<int, 32>{});
+    else key = block_kth_largest([&](int64_t i) { return f2key(sm[i]); }, n_sets_used, k, hist, bc, &n_gt);
     if (threadIdx.x == 0) {
         const float v = key2f(key);
         tau[q] = v > -INFINITY ? v - two_e_scaled : -INFINITY;
