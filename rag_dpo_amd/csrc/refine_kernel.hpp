@@ -267,9 +267,11 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ part_sc
         base[n_parts] = acc;
     }
     __syncthreads();
-    for (int p = 0; p < n_parts; ++p) {
-        const int c = base[p + 1] - base[p];
-        for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    // one thread per (part, slot): every load of the gather in flight at once (part after part, k threads at a time, it was
+    // n_parts dependent round trips)
+    for (int t = threadIdx.x; t < n_parts * k; t += blockDim.x) {
+        const int p = t / k, i = t - p * k;
+        if (i < base[p + 1] - base[p]) {
             s_s[base[p] + i] = part_score[(int64_t)p * stride_s + q * k + i];
             s_r[base[p] + i] = part_row[(int64_t)p * stride_r + q * k + i];
         }
