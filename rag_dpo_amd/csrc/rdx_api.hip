@@ -801,10 +801,10 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     // small problems and huge k are served by the exact full scan alone (one fp32 read of the corpus)
     // Round 2 re-measured the crossover (B = 4: exact path 0.060 / 0.099 / 0.129 ms at 24 k / 40 k / 60 k rows, MFMA path 0.081 / 0.085 /
     // 0.087): the exact path costs ceil(nq / 4) passes of (1.28 us per 1000 rows + 10 us) on top of what both paths share, the
-    // MFMA path ~67 us more than that share whatever the size — and beyond 32 Ki rows the select no longer holds a score row in
+    // MFMA path ~60 us more than that share whatever the size — and beyond 32 Ki rows the select no longer holds a score row in
     // registers. (The rule it replaces, nq * rows <= 4 M below 64 Ki rows, sent 64 queries x 60 k rows through 16 exact passes.)
     const int64_t exact_passes = (nq + 3) / 4;
-    const bool small = h->rows <= 32768 && (double)exact_passes * ((double)h->rows * 1.28e-3 + 10.0) <= 67.0;   // (any size: 600 queries on 1000 rows are 150 passes)
+    const bool small = h->rows <= 32768 && (double)exact_passes * ((double)h->rows * 1.28e-3 + 10.0) <= 60.0;   // (any size: 600 queries on 1000 rows are 150 passes)
     const bool exact_only = h->force_exact || k > K_FAST_MAX || k == 0 || h->rows < 1 || (small && !h->force_fast);
     int64_t sample_rows = 0;
     int grid = 0, G = 0, nqt = 0;
