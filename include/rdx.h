@@ -45,7 +45,7 @@ extern "C" {
 #define RDX_HOST 0
 #define RDX_DEVICE 1
 
-#define RDX_ABI_VERSION 1
+#define RDX_ABI_VERSION 2 /* 2: flags word in the packed partial, rdx_signal, rdx_search_async(out_flags) */
 
 typedef struct rdx_index rdx_index; /* opaque: one corpus shard resident in one GPU's HBM */
 
@@ -147,23 +147,45 @@ int rdx_search_masked(rdx_index* h, const float* queries, int64_t nq, int k, con
  * search has completed and runs its host half: when some queries' candidate segments overflowed (rare: clustered corpora) it
  * re-runs them through the fallback passes, synchronises the stream and reports *redone = 1 — results written by the first
  * pass were incomplete for those queries, so whatever consumed them on the stream must be re-enqueued. Any other call on
- * the index completes a pending search first. rdx_search == rdx_search_async + rdx_search_wait for device callers. */
+ * the index completes a pending search first. rdx_search == rdx_search_async + rdx_search_wait for device callers.
+ * Lifetimes: `queries` is consumed by the kernels rdx_search_async enqueues (the fallback passes work from the index's own
+ * normalised copy), so the caller may overwrite or free it with any STREAM-ORDERED work enqueued afterwards; the three output
+ * buffers and out_flags must stay valid until rdx_search_wait has returned (the host half may rewrite them).
+ * out_flags: NULL, or int32[RDX_PACKED_FLAGS] on the device. The search's last kernel stores out_flags[0] = 1 when the
+ * results are incomplete and rdx_search_wait WILL redo them (exactly the cases in which it reports *redone = 1), else 0;
+ * [1..3] = 0. rdx_search_wait stores 0 again once the fallback passes are enqueued: a consumer ordered after it sees
+ * "complete". With the partial laid out as below the word travels with the all-gather, and every rank learns from the
+ * merge (rdx_signal) whether ANY rank's partial was incomplete — no second collective, no device-to-host copy per step. */
+#define RDX_PACKED_FLAGS 4
 int rdx_search_async(rdx_index* h, const float* queries, int64_t nq, int k, const rdx_mask* mask, float* out_score,
-                     int64_t* out_row, int32_t* out_count, void* stream);
+                     int64_t* out_row, int32_t* out_count, int32_t* out_flags, void* stream);
 int rdx_search_wait(rdx_index* h, int* redone);
 
 /* Multi-GPU exchange step: merge n_parts per-shard partial results (after the RCCL all-gather,
  * SURVEY.md §8e) into the global top-k with the same ordering rule. Layouts:
- * part_score/part_row [n_parts][nq][k], part_count [n_parts][nq]; row ids must already be global. */
+ * part_score/part_row [n_parts][nq][k], part_count [n_parts][nq]; row ids must already be global (no row in two parts).
+ * n_parts <= 64, k <= 4096; when n_parts * k exceeds 4096 the parts are folded pairwise (same result, more launches). */
 int rdx_merge_topk(int device, const float* part_score, const int64_t* part_row,
                    const int32_t* part_count, int n_parts, int64_t nq, int k, float* out_score,
                    int64_t* out_row, int32_t* out_count, int space, void* stream);
 
+/* A word in pinned host memory that a kernel publishes and the host waits on (spin, then stream synchronise): how the
+ * merge tells the host whether any rank's partial carried the "incomplete" flag. One signal serves one stream of merges. */
+typedef struct rdx_signal rdx_signal;
+int rdx_signal_create(int device, rdx_signal** out);
+int rdx_signal_destroy(rdx_signal* s);
+/* blocks until the LAST rdx_merge_topk_packed given `s` has published; *value = OR over the parts of flags[0]. `stream` = the
+ * stream that merge was enqueued on (synchronised only if the word has not arrived after ~0.4 ms of spinning). */
+int rdx_signal_wait(rdx_signal* s, void* stream, int32_t* value);
+
 /* Same merge, reading the partials straight out of the all-gather receive buffer (device memory):
  * part p starts part_stride bytes (multiple of 16) after part p-1 and is one rank's packed contribution
- * rows int64[nq][k] | scores f32[nq][k] | counts int32[nq]. Outputs are device pointers; k >= 1. */
+ * rows int64[nq][k] | scores f32[nq][k] | counts int32[nq] | flags int32[RDX_PACKED_FLAGS]
+ * (= nq*k*12 + nq*4 + 16 bytes). Outputs are device pointers; k >= 1. sig: NULL, or the signal through which the first block
+ * publishes the OR of the parts' flags[0] as soon as it has read them (the decision "some partial was incomplete: exchange
+ * again" does not wait for the merge itself). */
 int rdx_merge_topk_packed(int device, const void* packed, int64_t part_stride, int n_parts, int64_t nq,
-                          int k, float* out_score, int64_t* out_row, int32_t* out_count, void* stream);
+                          int k, float* out_score, int64_t* out_row, int32_t* out_count, rdx_signal* sig, void* stream);
 
 /* Diagnostics of the last rdx_search on this index (valid after the stream has synchronised). */
 typedef struct rdx_search_stats {

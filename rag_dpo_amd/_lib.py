@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get("RDX_LIB_PATH") or os.path.join(_HERE, "librdx.so")
 
 RDX_OK, RDX_ERR_INVALID, RDX_ERR_HIP, RDX_ERR_NOMEM, RDX_ERR_STATE = 0, 1, 2, 3, 4
 RDX_HOST, RDX_DEVICE = 0, 1
+ABI_VERSION = 2          # include/rdx.h RDX_ABI_VERSION
+PACKED_FLAGS = 4         # include/rdx.h RDX_PACKED_FLAGS: int32 words behind the counts of a packed partial
 
 
 class RdxUnavailable(RuntimeError):
@@ -69,10 +71,13 @@ SYMBOLS = {
     "rdx_mask_create": (_i, [_vp, _vp, _i, ctypes.POINTER(_vp)]),
     "rdx_mask_destroy": (_i, [_vp]),
     "rdx_search_masked": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
-    "rdx_search_async": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rdx_search_async": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdx_search_wait": (_i, [_vp, ctypes.POINTER(_i)]),
     "rdx_merge_topk": (_i, [_i, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _vp]),
-    "rdx_merge_topk_packed": (_i, [_i, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    "rdx_signal_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "rdx_signal_destroy": (_i, [_vp]),
+    "rdx_signal_wait": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_int32)]),
+    "rdx_merge_topk_packed": (_i, [_i, _vp, _i64, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp]),
     "rdx_search_last_stats": (_i, [_vp, ctypes.POINTER(SearchStats)]),
 }
 
@@ -93,8 +98,8 @@ def load(require_gpu: bool = True):
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.rdx_version() != 1:
-            raise RdxUnavailable(f"librdx ABI version {L.rdx_version()} != 1: rebuild the library")
+        if L.rdx_version() != ABI_VERSION:
+            raise RdxUnavailable(f"librdx ABI version {L.rdx_version()} != {ABI_VERSION}: rebuild the library")
         _lib = L
     if require_gpu:
         n = ctypes.c_int(0)

@@ -562,12 +562,12 @@ class Collection:
     def _cur_names(self):
         return self._names(self._gen if self._snap_format >= 3 else None)   # format 2 stores (round 1) had one unnamed generation
 
-    def _write_header(self, path: str, rows: int):
+    def _write_header(self, path: str, rows: int, fmt: Optional[int] = None, gen: Optional[int] = None):
         os.makedirs(path, exist_ok=True)
         tmp = os.path.join(path, "collection.json.tmp")
         with open(tmp, "w", encoding="utf-8") as f:
             json.dump({"name": self.name, "metadata": self.metadata, "dim": self._dim, "rows": rows,
-                       "format": self._snap_format, "gen": self._gen}, f)
+                       "format": self._snap_format if fmt is None else fmt, "gen": self._gen if gen is None else gen}, f)
             f.flush()
             os.fsync(f.fileno())
         os.replace(tmp, os.path.join(path, "collection.json"))
@@ -600,25 +600,35 @@ class Collection:
                 self._compact()
             os.makedirs(path, exist_ok=True)
             old = self._cur_names()
-            self._snap_format = 3
-            self._gen += 1
-            nm = self._names(self._gen)
+            # The object moves to generation g+1 only AFTER the header naming it is on disk. Until then every add / update /
+            # delete must keep going to journal<g>, which collection.json still names: a snapshot that fails half way (ENOSPC
+            # in np.save, say) leaves the store exactly as it was, and the writes acknowledged afterwards are found again.
+            new_gen = self._gen + 1
+            nm = self._names(new_gen)
             n = self._rows
-            if n:
-                emb = self._engine.get(np.arange(n, dtype=np.int64))   # the stored (normalised) fp32 rows
-                with open(os.path.join(path, nm["emb"]), "wb") as f:
-                    np.save(f, emb)
+            try:
+                if n:
+                    emb = self._engine.get(np.arange(n, dtype=np.int64))   # the stored (normalised) fp32 rows
+                    with open(os.path.join(path, nm["emb"]), "wb") as f:
+                        np.save(f, emb)
+                        f.flush()
+                        os.fsync(f.fileno())
+                with open(os.path.join(path, nm["rec"]), "w", encoding="utf-8") as f:
+                    for r in range(n):
+                        f.write(json.dumps({"id": self._ids[r], "document": self._docs[r], "metadata": self._meta_of(r)},
+                                           ensure_ascii=False) + "\n")
                     f.flush()
                     os.fsync(f.fileno())
-            with open(os.path.join(path, nm["rec"]), "w", encoding="utf-8") as f:
-                for r in range(n):
-                    f.write(json.dumps({"id": self._ids[r], "document": self._docs[r], "metadata": self._meta_of(r)},
-                                       ensure_ascii=False) + "\n")
-                f.flush()
-                os.fsync(f.fileno())
-            _fsync_dir(path)                      # the new generation's files exist before the header can name them
-            self._write_header(path, n)          # commit point: the header names generation g+1
-            self._snap_rows = n
+                _fsync_dir(path)                      # the new generation's files exist before the header can name them
+                self._write_header(path, n, fmt=3, gen=new_gen)   # commit point: the header names generation g+1
+            except BaseException:
+                for fn in (nm["emb"], nm["rec"], "collection.json.tmp"):   # partial files of the generation that never committed
+                    try:
+                        os.remove(os.path.join(path, fn))
+                    except OSError:
+                        pass
+                raise
+            self._snap_format, self._gen, self._snap_rows = 3, new_gen, n
             for fn in old.values():
                 fp = os.path.join(path, fn)
                 if os.path.exists(fp):

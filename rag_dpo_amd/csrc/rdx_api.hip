@@ -105,6 +105,7 @@ struct PendingSearch {
     float* d_score = nullptr;
     int64_t* d_row = nullptr;
     int32_t* d_count = nullptr;
+    int32_t* d_flags = nullptr;    // rdx_search_async(out_flags): the "incomplete" word of the packed partial, or NULL
     hipStream_t st = nullptr;
     unsigned long long seq = 0;
     bool exact_only = false, balance = false, ride = false, big_host_copy = false;
@@ -168,6 +169,14 @@ struct rdx_mask {
     int device = 0;
     int64_t rows = 0;   // row count of the index when the mask was made: a mask never outlives a write to the index
     DevBuf words;
+};
+
+// a pinned, device-visible word the merge kernel publishes ((sequence << 1) | value) and the host waits on
+struct rdx_signal {
+    int device = 0;
+    unsigned long long* host = nullptr;
+    unsigned long long* dev = nullptr;
+    unsigned long long seq = 0;   // number of the last merge that was given this signal
 };
 
 static int finish_pending(rdx_index* h, bool* redone);   // (search section)
@@ -346,6 +355,7 @@ extern "C" int rdx_index_reserve(rdx_index* h, int64_t rows) {
 extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t value) {
     if (!h || !name) return fail(RDX_ERR_INVALID, "rdx_index_set_option: null pointer");
     std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(finish_pending(h, nullptr));   // the host half of an asynchronous search reads the options it was enqueued under
     const std::string n(name);
     if (n == "force_exact") h->force_exact = value != 0;
     else if (n == "force_fast") h->force_fast = value != 0;
@@ -482,6 +492,7 @@ extern "C" int rdx_index_get(rdx_index* h, const int64_t* row_ids, int64_t n, fl
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (n == 0) return RDX_OK;
     std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(finish_pending(h, nullptr));
     RDX_TRY(set_device(h));
     hipStream_t st = h->own_stream;
     const int64_t* d_ids = nullptr;
@@ -558,15 +569,20 @@ extern "C" int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int6
     std::lock_guard<std::mutex> lk(h->mu);
     if (first_row + n > h->rows) return fail(RDX_ERR_INVALID, "rdx_index_set_row_ids: rows [first_row, first_row + n) must exist");
     if (n == 0) return RDX_OK;
+    RDX_TRY(finish_pending(h, nullptr));   // k_refine / k_select_dense of an asynchronous search may still be reading the map
     RDX_TRY(set_device(h));
     hipStream_t st = h->own_stream;
-    if (space == RDX_HOST) {
-        for (int64_t i = 0; i < n; ++i)
-            if (ids[i] < 0 || (i > 0 && ids[i] <= ids[i - 1]))
-                return fail(RDX_ERR_INVALID, "rdx_index_set_row_ids: ids must be non-negative and strictly increasing");
-    } else {
+    std::vector<int64_t> tmp;
+    const int64_t* host_ids = ids;
+    if (space == RDX_DEVICE) {
         HIP_TRY(hipDeviceSynchronize());   // the caller's producer of `ids` (any stream) is done
+        tmp.resize((size_t)n);             // the merge's tie order rests on the map being increasing: checked for device ids too
+        HIP_TRY(hipMemcpy(tmp.data(), ids, (size_t)n * 8, hipMemcpyDeviceToHost));
+        host_ids = tmp.data();
     }
+    for (int64_t i = 0; i < n; ++i)
+        if (host_ids[i] < 0 || (i > 0 && host_ids[i] <= host_ids[i - 1]))
+            return fail(RDX_ERR_INVALID, "rdx_index_set_row_ids: ids must be non-negative and strictly increasing");
     if (!h->row_map) {
         HIP_TRY(hipMalloc((void**)&h->row_map, (size_t)std::max<int64_t>(h->cap, 256) * 8));
         hipLaunchKernelGGL(k_iota64, dim3((unsigned)((h->cap + 255) / 256)), dim3(256), 0, st, h->row_map, (int64_t)0, h->cap, h->row_base);
@@ -582,7 +598,8 @@ struct NormScratch {
     std::mutex mu;
     DevBuf in, out, bad;
 };
-static NormScratch g_norm[64];
+// (never destroyed: a static destructor would call hipFree at process exit, possibly after the HIP runtime is gone)
+static NormScratch* const g_norm = new NormScratch[64];
 
 extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space, void* stream) {
     if (n < 0 || (n > 0 && (!in || !out))) return fail(RDX_ERR_INVALID, "rdx_l2_normalize: bad argument");
@@ -765,12 +782,30 @@ static int wait_search(rdx_index* h, hipStream_t st, unsigned long long seq) {
 }
 
 // depth 0 = the caller's batch; depth 1 = the second-chance batch of queries whose candidate segments overflowed
-static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stats* acc_stats, HostOut* ho, bool* redone);
+static int complete_chunk_impl(rdx_index* h, const PendingSearch& ps, rdx_search_stats* acc_stats, HostOut* ho, bool* redone);
+// The counter block is zeroed once and afterwards by the k_finish of every search. A search that leaves early (allocation
+// failure, launch error, an internal check) may have skipped its k_finish: the next search zeroes the block itself again.
+static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stats* acc_stats, HostOut* ho, bool* redone) {
+    const int rc = complete_chunk_impl(h, ps, acc_stats, ho, redone);
+    if (rc != RDX_OK) h->ctr_ready = false;
+    return rc;
+}
 
 // `defer`: return as soon as everything up to k_finish is enqueued; the host half is left in h->pending (rdx_search_async)
+static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, int k, const uint32_t* d_allow, float* d_score,
+                             int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth,
+                             HostOut* ho, bool defer, int32_t* d_flags);
 static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k, const uint32_t* d_allow, float* d_score,
                         int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth = 0,
-                        HostOut* ho = nullptr, bool defer = false) {
+                        HostOut* ho = nullptr, bool defer = false, int32_t* d_flags = nullptr) {
+    const int rc = search_chunk_impl(h, d_queries, nq, k, d_allow, d_score, d_row, d_count, st, acc_stats, depth, ho, defer, d_flags);
+    if (rc != RDX_OK) h->ctr_ready = false;
+    return rc;
+}
+
+static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, int k, const uint32_t* d_allow, float* d_score,
+                             int64_t* d_row, int32_t* d_count, hipStream_t st, rdx_search_stats* acc_stats, int depth,
+                             HostOut* ho, bool defer, int32_t* d_flags) {
     const int nq_pad = (int)((nq + 255) / 256 * 256);
     const bool prof_all = h->profile == 1 && depth == 0, prof_main = (h->profile == 1 || h->profile == 2) && depth == 0;
     const bool prof_stamps = h->profile == 3 && depth == 0;   // the kernels stamp their own times: nothing extra on the stream
@@ -794,7 +829,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     mark(0);
     hipLaunchKernelGGL(k_normalize<true>, dim3((int)((nq_pad + 3) / 4)), dim3(256), 0, st, d_queries, (const uint16_t*)nullptr, nq, h->dim,
                        (const int64_t*)nullptr, (int64_t)0, MasterView{h->qhat.as<float>(), nullptr, nullptr}, h->qshadow.as<_Float16>(), h->ksteps, h->scale(),
-                       d_bad, (int64_t)nq_pad);
+                       d_bad, (int64_t)nq_pad, depth > 0 ? 1 : 0);   // depth 1: the rows ARE normalised queries (gathered from qhat): kept bit for bit
     HIP_TRY(hipGetLastError());
     mark(1);
 
@@ -926,7 +961,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
             }
             p.xlo[8] = (int)n_tiles;
         }
-        if (prof_stamps && !balance) {
+        if (prof_stamps && !balance && grid <= 512) {   // (Mailbox::wg_times holds 1024 stamps)
             RDX_TRY(h->wgt.ensure((size_t)grid * 16));
             p.wgt = h->wgt.as<unsigned long long>();
         }
@@ -959,12 +994,13 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
         }
         HIP_TRY(hipMemcpyAsync(ho->count, d_count, b_c, hipMemcpyDeviceToHost, st));
     }
+    const bool stamps = (balance || (prof_stamps && !exact_only)) && grid <= 512;
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, st, h->ctr.as<RefineCounters>(), h->mbox_dev, seq,
-                       (balance || (prof_stamps && !exact_only)) ? h->wgt.as<unsigned long long>() : (const unsigned long long*)nullptr,
-                       (balance || (prof_stamps && !exact_only)) ? 2 * grid : 0,
+                       stamps ? h->wgt.as<unsigned long long>() : (const unsigned long long*)nullptr, stamps ? 2 * grid : 0,
                        reinterpret_cast<const uint32_t*>(d_row), reinterpret_cast<uint32_t*>(h->pin_out_dev), (int64_t)(ride ? b_r / 4 : 0),
                        reinterpret_cast<const uint32_t*>(d_score), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r), (int64_t)(ride ? b_s / 4 : 0),
-                       reinterpret_cast<const uint32_t*>(d_count), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r + b_s), (int64_t)(ride ? b_c / 4 : 0));
+                       reinterpret_cast<const uint32_t*>(d_count), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r + b_s), (int64_t)(ride ? b_c / 4 : 0),
+                       depth == 0 ? d_flags : (int32_t*)nullptr, (!exact_only && depth == 0) ? 1 : 0);
     HIP_TRY(hipGetLastError());
     PendingSearch ps;
     ps.active = true;
@@ -975,6 +1011,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
     ps.d_score = d_score;
     ps.d_row = d_row;
     ps.d_count = d_count;
+    ps.d_flags = depth == 0 ? d_flags : nullptr;
     ps.st = st;
     ps.seq = seq;
     ps.exact_only = exact_only;
@@ -998,8 +1035,7 @@ static int search_chunk(rdx_index* h, const float* d_queries, int64_t nq, int k,
 }
 
 // the host half of a search (see PendingSearch). *redone (if given) = a fallback pass rewrote results after k_finish.
-static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stats* acc_stats, HostOut* ho, bool* redone) {
-    const float* d_queries = ps.d_queries;
+static int complete_chunk_impl(rdx_index* h, const PendingSearch& ps, rdx_search_stats* acc_stats, HostOut* ho, bool* redone) {
     const int64_t nq = ps.nq;
     const int k = ps.k, depth = ps.depth, grid = ps.grid, G = ps.G, nqt = ps.nqt;
     const uint32_t* d_allow = ps.d_allow;
@@ -1021,6 +1057,21 @@ static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stat
     const Mailbox& mb = *h->mbox;
     const unsigned long long c_emitted = mb.emitted, c_rescored = mb.rescored;
     const int c_bad = mb.bad;
+    // profile = 3: the kernels' own stamps, read NOW — a second-chance pass below runs a nested search whose k_finish overwrites the mailbox
+    float stamp_ms_exact = 0.f, stamp_ms_main = 0.f;
+    if (prof_stamps) {
+        if (exact_only) {
+            if (mb.t_last > mb.t_first) stamp_ms_exact = (float)((double)(mb.t_last - mb.t_first) * 1e-5);
+        } else if (grid <= 512) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int b = 0; b < grid; ++b) {
+                if ((b >> 3) >= G * nqt) continue;   // idle workgroups return before they stamp
+                t0 = std::min(t0, mb.wg_times[2 * b]);
+                t1 = std::max(t1, mb.wg_times[2 * b + 1]);
+            }
+            if (t1 > t0) stamp_ms_main = (float)((double)(t1 - t0) * 1e-5);
+        }
+    }
     if (mb.oob) return fail(RDX_ERR_STATE, "internal: the scan computed a corpus address outside the scan copy (RDX_CHECK_BOUNDS build)");
     int n_exact = exact_only ? (int)nq : mb.n_exact;
     if (ride) {
@@ -1078,7 +1129,9 @@ static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stat
             RDX_TRY(h->r_r.ensure((size_t)m * kk * 8));
             RDX_TRY(h->r_c.ensure((size_t)m * 4));
             HIP_TRY(hipMemcpyAsync(h->r_list.p, h->exact_list.p, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_gather_queries, dim3((m + 3) / 4), dim3(256), 0, st, d_queries, h->r_list.as<int32_t>(), m, h->dim,
+            // from the index's own normalised copy (qhat), not from the caller's buffer: an asynchronous caller may have reused
+            // that since (include/rdx.h "Lifetimes"); the nested search stores these rows verbatim, so its scores have the same bits
+            hipLaunchKernelGGL(k_gather_queries, dim3((m + 3) / 4), dim3(256), 0, st, h->qhat.as<float>(), h->r_list.as<int32_t>(), m, h->dim,
                                h->r_q.as<float>());
             HIP_TRY(hipGetLastError());
             rdx_search_stats sub = {};
@@ -1087,6 +1140,7 @@ static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stat
             hipLaunchKernelGGL(k_scatter_topk, dim3(m), dim3(64), 0, st, h->r_s.as<float>(), h->r_r.as<int64_t>(), h->r_c.as<int32_t>(),
                                h->r_list.as<int32_t>(), m, k, d_score, d_row, d_count);
             HIP_TRY(hipGetLastError());
+            if (ps.d_flags) HIP_TRY(hipMemsetAsync(ps.d_flags, 0, 16, st));   // the partial is complete now
             HIP_TRY(hipStreamSynchronize(st));   // rdx_search returns with the stream drained
             acc_stats->retried_queries += m;
             acc_stats->emitted += sub.emitted;
@@ -1094,6 +1148,7 @@ static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stat
             n_exact = (int)sub.exact_queries;
         } else if (n_exact > 0 && !c_bad) {
             RDX_TRY(run_exact(h, h->exact_list.as<int32_t>(), n_exact, k, d_allow, d_score, d_row, d_count, st));
+            if (ps.d_flags) HIP_TRY(hipMemsetAsync(ps.d_flags, 0, 16, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
         acc_stats->scan_main_launch_rows = h->rows;
@@ -1130,17 +1185,8 @@ static int complete_chunk(rdx_index* h, const PendingSearch& ps, rdx_search_stat
     } else if (prof_stamps) {
         // first workgroup start -> last workgroup end of the dominant kernel(s), from the kernels' own 100 MHz stamps
         acc_stats->profiled = 3;
-        if (exact_only) {
-            if (mb.t_last > mb.t_first) acc_stats->ms_exact += (float)((double)(mb.t_last - mb.t_first) * 1e-5);
-        } else {
-            unsigned long long t0 = ~0ull, t1 = 0;
-            for (int b = 0; b < grid; ++b) {
-                if ((b >> 3) >= G * nqt) continue;   // idle workgroups return before they stamp
-                t0 = std::min(t0, mb.wg_times[2 * b]);
-                t1 = std::max(t1, mb.wg_times[2 * b + 1]);
-            }
-            if (t1 > t0) acc_stats->ms_scan_main += (float)((double)(t1 - t0) * 1e-5);
-        }
+        acc_stats->ms_exact += stamp_ms_exact;
+        acc_stats->ms_scan_main += stamp_ms_main;
     }
     return RDX_OK;
 }
@@ -1232,7 +1278,7 @@ extern "C" int rdx_search(rdx_index* h, const float* queries, int64_t nq, int k,
 }
 
 extern "C" int rdx_search_async(rdx_index* h, const float* queries, int64_t nq, int k, const rdx_mask* mask, float* out_score,
-                                int64_t* out_row, int32_t* out_count, void* stream) {
+                                int64_t* out_row, int32_t* out_count, int32_t* out_flags, void* stream) {
     if (!h) return fail(RDX_ERR_INVALID, "rdx_search_async: null index");
     if (nq < 1 || nq > 4096 || k < 0 || k > SELECT_MAX_K) return fail(RDX_ERR_INVALID, "rdx_search_async: 1 <= nq <= 4096, 0 <= k <= " + std::to_string(SELECT_MAX_K));
     if (!queries || !out_count || (k > 0 && (!out_score || !out_row))) return fail(RDX_ERR_INVALID, "rdx_search_async: null pointer");
@@ -1250,7 +1296,7 @@ extern "C" int rdx_search_async(rdx_index* h, const float* queries, int64_t nq, 
     s.k = k;
     s.rows = h->rows;
     return search_chunk(h, queries, nq, k, mask ? mask->words.as<uint32_t>() : nullptr, out_score, out_row, out_count, (hipStream_t)stream, &s, 0,
-                        nullptr, true);
+                        nullptr, true, out_flags);
 }
 
 extern "C" int rdx_search_wait(rdx_index* h, int* redone) {
@@ -1266,6 +1312,7 @@ extern "C" int rdx_mask_create(rdx_index* h, const uint32_t* allow_bits, int spa
     if (!h || !allow_bits || !out) return fail(RDX_ERR_INVALID, "rdx_mask_create: null pointer");
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(finish_pending(h, nullptr));
     RDX_TRY(set_device(h));
     rdx_mask* m = new rdx_mask();
     m->device = h->device;
@@ -1325,8 +1372,7 @@ extern "C" int rdx_search_last_stats(rdx_index* h, rdx_search_stats* out) {
 
 extern "C" int rdx_merge_topk(int device, const float* part_score, const int64_t* part_row, const int32_t* part_count, int n_parts,
                               int64_t nq, int k, float* out_score, int64_t* out_row, int32_t* out_count, int space, void* stream) {
-    if (n_parts < 1 || n_parts > 64 || nq < 0 || k < 0) return fail(RDX_ERR_INVALID, "rdx_merge_topk: bad shape");
-    if ((int64_t)n_parts * k > MERGE_MAX) return fail(RDX_ERR_INVALID, "rdx_merge_topk: n_parts * k exceeds " + std::to_string(MERGE_MAX));
+    if (n_parts < 1 || n_parts > 64 || nq < 0 || k < 0 || k > SELECT_MAX_K) return fail(RDX_ERR_INVALID, "rdx_merge_topk: bad shape");
     if (space != RDX_HOST && space != RDX_DEVICE) return fail(RDX_ERR_INVALID, "space must be RDX_HOST or RDX_DEVICE");
     if (nq == 0) return RDX_OK;
     if (!part_count || !out_count || (k > 0 && (!part_score || !part_row || !out_score || !out_row)))
@@ -1361,9 +1407,36 @@ extern "C" int rdx_merge_topk(int device, const float* part_score, const int64_t
         d_or = orow.as<int64_t>();
         d_oc = oc.as<int32_t>();
     }
-    hipLaunchKernelGGL(k_merge, dim3((int)nq), dim3(256), 0, st, d_ps, d_pr, d_pc, (int64_t)nq * k, (int64_t)nq * k, (int64_t)nq, n_parts, nq, k,
-                       d_os, d_or, d_oc);
-    HIP_TRY(hipGetLastError());
+    DevBuf t_s[2], t_r[2], t_c[2];   // the fold's intermediate lists (large k only)
+    if ((int64_t)n_parts * k <= MERGE_MAX) {
+        hipLaunchKernelGGL(k_merge, dim3((int)nq), dim3(256), 0, st, d_ps, d_pr, d_pc, (int64_t)nq * k, (int64_t)nq * k, (int64_t)nq, n_parts, nq, k,
+                           d_os, d_or, d_oc);
+        HIP_TRY(hipGetLastError());
+    } else {
+        // more candidates per query than k_merge ranks in LDS (several shards at k > 2048 / n_parts): fold the parts pairwise
+        const size_t nk = (size_t)nq * k;
+        for (int j = 0; j < 2 && n_parts > 2; ++j) {
+            RDX_TRY(t_s[j].ensure(nk * 4));
+            RDX_TRY(t_r[j].ensure(nk * 8));
+            RDX_TRY(t_c[j].ensure((size_t)nq * 4));
+        }
+        const float* a_s = d_ps;
+        const int64_t* a_r = d_pr;
+        const int32_t* a_c = d_pc;
+        for (int p = 1; p < n_parts; ++p) {
+            const bool last = p == n_parts - 1;
+            float* o_s = last ? d_os : t_s[p & 1].as<float>();
+            int64_t* o_r = last ? d_or : t_r[p & 1].as<int64_t>();
+            int32_t* o_c = last ? d_oc : t_c[p & 1].as<int32_t>();
+            hipLaunchKernelGGL(k_merge_pair, dim3((int)nq), dim3(256), 0, st, a_s, a_r, a_c, d_ps + (size_t)p * nk, d_pr + (size_t)p * nk,
+                               d_pc + (size_t)p * nq, k, o_s, o_r, o_c);
+            HIP_TRY(hipGetLastError());
+            a_s = o_s;
+            a_r = o_r;
+            a_c = o_c;
+        }
+        if (space == RDX_DEVICE && n_parts > 2) HIP_TRY(hipStreamSynchronize(st));   // the intermediates are freed on return
+    }
     if (space == RDX_HOST) {
         if (k > 0) {
             HIP_TRY(hipMemcpyAsync(out_score, d_os, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
@@ -1376,20 +1449,76 @@ extern "C" int rdx_merge_topk(int device, const float* part_score, const int64_t
     return RDX_OK;
 }
 
-// the packed layout one rank contributes to the all-gather: rows i64[nq][k] | scores f32[nq][k] | counts i32[nq]
+extern "C" int rdx_signal_create(int device, rdx_signal** out) {
+    if (!out) return fail(RDX_ERR_INVALID, "rdx_signal_create: null out pointer");
+    HIP_TRY(hipSetDevice(device));
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(p, 0, 64);
+    void* d = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&d, p, 0);
+    if (e != hipSuccess) {
+        (void)hipHostFree(p);
+        return fail(RDX_ERR_HIP, std::string("hipHostGetDevicePointer: ") + hipGetErrorString(e));
+    }
+    rdx_signal* s = new rdx_signal();
+    s->device = device;
+    s->host = reinterpret_cast<unsigned long long*>(p);
+    s->dev = reinterpret_cast<unsigned long long*>(d);
+    *out = s;
+    return RDX_OK;
+}
+
+extern "C" int rdx_signal_destroy(rdx_signal* s) {
+    if (!s) return RDX_OK;
+    (void)hipSetDevice(s->device);
+    if (s->host) (void)hipHostFree(s->host);
+    delete s;
+    return RDX_OK;
+}
+
+extern "C" int rdx_signal_wait(rdx_signal* s, void* stream, int32_t* value) {
+    if (!s || !value) return fail(RDX_ERR_INVALID, "rdx_signal_wait: null pointer");
+    if (s->seq == 0) return fail(RDX_ERR_STATE, "rdx_signal_wait: no merge has been given this signal");
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long w = 0;
+    for (unsigned spins = 1;; ++spins) {
+        w = __atomic_load_n(s->host, __ATOMIC_ACQUIRE);
+        if ((w >> 1) == s->seq) break;
+        _mm_pause();
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
+            HIP_TRY(hipSetDevice(s->device));
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            w = __atomic_load_n(s->host, __ATOMIC_ACQUIRE);
+            if ((w >> 1) != s->seq) return fail(RDX_ERR_HIP, "internal: the merge completed without publishing its signal");
+            break;
+        }
+    }
+    *value = (int32_t)(w & 1ull);
+    return RDX_OK;
+}
+
+// the packed layout one rank contributes to the all-gather: rows i64[nq][k] | scores f32[nq][k] | counts i32[nq] | flags i32[4]
 extern "C" int rdx_merge_topk_packed(int device, const void* packed, int64_t part_stride, int n_parts, int64_t nq, int k,
-                                     float* out_score, int64_t* out_row, int32_t* out_count, void* stream) {
+                                     float* out_score, int64_t* out_row, int32_t* out_count, rdx_signal* sig, void* stream) {
     if (n_parts < 1 || n_parts > 64 || nq < 0 || k < 1) return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: bad shape");
     if ((int64_t)n_parts * k > MERGE_MAX) return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: n_parts * k exceeds " + std::to_string(MERGE_MAX));
-    if (part_stride % 16 != 0 || part_stride < nq * k * 12 + nq * 4)
-        return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: part_stride must be a multiple of 16 covering one packed partial");
-    if (nq == 0) return RDX_OK;
+    const int64_t flags_off = nq * k * 12 + nq * 4;
+    if (part_stride % 16 != 0 || part_stride < flags_off + 4 * RDX_PACKED_FLAGS)
+        return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: part_stride must be a multiple of 16 covering one packed partial (rows | scores | counts | flags)");
+    if (sig && sig->device != device) return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: the signal belongs to another device");
+    if (nq == 0) {
+        if (sig) return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: a signal needs nq >= 1");
+        return RDX_OK;
+    }
     if (!packed || !out_score || !out_row || !out_count) return fail(RDX_ERR_INVALID, "rdx_merge_topk_packed: null pointer");
     HIP_TRY(hipSetDevice(device));
     const char* b = reinterpret_cast<const char*>(packed);
+    const unsigned long long seq = sig ? ++sig->seq : 0;
     hipLaunchKernelGGL(k_merge, dim3((int)nq), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float*>(b + nq * k * 8),
                        reinterpret_cast<const int64_t*>(b), reinterpret_cast<const int32_t*>(b + nq * k * 12), part_stride / 4,
-                       part_stride / 8, part_stride / 4, n_parts, nq, k, out_score, out_row, out_count);
+                       part_stride / 8, part_stride / 4, n_parts, nq, k, out_score, out_row, out_count,
+                       reinterpret_cast<const int32_t*>(b + flags_off), part_stride / 4, sig ? sig->dev : (unsigned long long*)nullptr, seq);
     HIP_TRY(hipGetLastError());
     return RDX_OK;
 }

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
                                                 const unsigned long long* __restrict__ wgt, int n_wgt,
                                                 const uint32_t* __restrict__ s0, uint32_t* __restrict__ d0, int64_t w0,
                                                 const uint32_t* __restrict__ s1, uint32_t* __restrict__ d1, int64_t w1,
-                                                const uint32_t* __restrict__ s2, uint32_t* __restrict__ d2, int64_t w2) {
+                                                const uint32_t* __restrict__ s2, uint32_t* __restrict__ d2, int64_t w2,
+                                                int32_t* __restrict__ out_flags, int may_redo) {
     for (int64_t i = threadIdx.x; i < w0; i += blockDim.x) d0[i] = s0[i];
     for (int64_t i = threadIdx.x; i < w1; i += blockDim.x) d1[i] = s1[i];
     for (int64_t i = threadIdx.x; i < w2; i += blockDim.x) d2[i] = s2[i];
@@ -52,6 +53,14 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        // rdx_search_async(out_flags): "this partial is incomplete, the host half will redo some queries" — the word travels with
+        // the packed partial through the all-gather (include/rdx.h); the same condition complete_chunk reports as *redone
+        if (out_flags) {
+            out_flags[0] = (may_redo && ctr->n_exact > 0 && !ctr->bad) ? 1 : 0;
+            out_flags[1] = 0;
+            out_flags[2] = 0;
+            out_flags[3] = 0;
+        }
         mb->emitted = ctr->emitted;
         mb->rescored = ctr->rescored;
         mb->n_exact = ctr->n_exact;
@@ -252,7 +261,16 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ part_sc
                                                const int32_t* __restrict__ part_count, int64_t stride_s, int64_t stride_r,
                                                int64_t stride_c, int n_parts, int64_t nq, int k,
                                                float* __restrict__ out_score, int64_t* __restrict__ out_row,
-                                               int32_t* __restrict__ out_count) {
+                                               int32_t* __restrict__ out_count, const int32_t* __restrict__ part_flags = nullptr,
+                                               int64_t stride_f = 0, unsigned long long* __restrict__ sig_word = nullptr,
+                                               unsigned long long sig_seq = 0) {
+    // rdx_signal: the first block tells the host, before it merges anything, whether some rank's partial carried the
+    // "incomplete" flag (one 64-bit word, sequence number and value together: nothing to order)
+    if (sig_word && blockIdx.x == 0 && threadIdx.x == 0) {
+        int any = 0;
+        for (int p = 0; p < n_parts; ++p) any |= part_flags[(int64_t)p * stride_f] != 0;
+        __hip_atomic_store(sig_word, (sig_seq << 1) | (unsigned long long)any, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __shared__ float s_s[MERGE_MAX];
     __shared__ int64_t s_r[MERGE_MAX];
     __shared__ int base[65];
@@ -278,6 +296,52 @@ __global__ __launch_bounds__(256) void k_merge(const float* __restrict__ part_sc
     }
     __syncthreads();
     rank_and_write(s_s, s_r, base[n_parts], k, out_score + q * k, out_row + q * k, out_count + q);
+}
+
+// C1b. merge of TWO partial lists per query when n_parts * k exceeds what k_merge ranks in LDS (k > 2048 with two parts, ...):
+// both lists are sorted (score desc, row asc) and no row occurs twice (row ids are global), so an element's place in the merged
+// list is its index in its own list plus the number of elements of the other list that come before it — one binary search per
+// element, no LDS. rdx_merge_topk folds the parts through this kernel one after the other. out must not alias a or b.
+__global__ __launch_bounds__(256) void k_merge_pair(const float* __restrict__ a_s, const int64_t* __restrict__ a_r,
+                                                    const int32_t* __restrict__ a_c, const float* __restrict__ b_s,
+                                                    const int64_t* __restrict__ b_r, const int32_t* __restrict__ b_c, int k,
+                                                    float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                                    int32_t* __restrict__ out_count) {
+    const int64_t q = blockIdx.x;
+    const int na = min(max(a_c[q], 0), k), nb = min(max(b_c[q], 0), k);
+    const float* as = a_s + q * k;
+    const float* bs = b_s + q * k;
+    const int64_t* ar = a_r + q * k;
+    const int64_t* br = b_r + q * k;
+    float* os = out_score + q * k;
+    int64_t* orow = out_row + q * k;
+    for (int t = threadIdx.x; t < na + nb; t += blockDim.x) {
+        const bool from_a = t < na;
+        const int i = from_a ? t : t - na;
+        const float s = from_a ? as[i] : bs[i];
+        const int64_t r = from_a ? ar[i] : br[i];
+        const float* xs = from_a ? bs : as;
+        const int64_t* xr = from_a ? br : ar;
+        int lo = 0, hi = from_a ? nb : na;   // first element of the other list that does NOT come before (s, r)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const float ms = xs[mid];
+            const bool before = ms > s || (ms == s && xr[mid] < r);
+            if (before) lo = mid + 1;
+            else hi = mid;
+        }
+        const int pos = i + lo;
+        if (pos < k) {
+            os[pos] = s;
+            orow[pos] = r;
+        }
+    }
+    const int c = na + nb < k ? na + nb : k;
+    for (int i = c + threadIdx.x; i < k; i += blockDim.x) {
+        os[i] = -INFINITY;
+        orow[i] = -1;
+    }
+    if (threadIdx.x == 0) out_count[q] = c;
 }
 
 }  // namespace rdx

@@ -181,18 +181,23 @@ class HipIndex:
                                      ctypes.c_void_p(out_score.data_ptr()), ctypes.c_void_p(out_row.data_ptr()),
                                      ctypes.c_void_p(out_count.data_ptr()), L.RDX_DEVICE, ctypes.c_void_p(stream)))
 
-    def search_device_async(self, queries, k: int, out_score, out_row, out_count):
-        """enqueue the search on the current torch stream and return at once; search_wait() completes it (include/rdx.h)"""
+    def search_device_async(self, queries, k: int, out_score, out_row, out_count, out_flags=None):
+        """enqueue the search on the current torch stream and return at once; search_wait() completes it (include/rdx.h).
+        `queries` may be reused by stream-ordered work enqueued afterwards; the outputs (and out_flags: int32[4] on the device,
+        [0] = 1 while the results are incomplete) must stay valid until search_wait() has returned."""
         import torch
         nq = queries.shape[0]
         assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
         assert out_score.shape == (nq, k) and out_score.dtype == torch.float32 and out_score.is_contiguous()
         assert out_row.shape == (nq, k) and out_row.dtype == torch.int64 and out_row.is_contiguous()
         assert out_count.shape == (nq,) and out_count.dtype == torch.int32
+        assert out_flags is None or (out_flags.numel() >= L.PACKED_FLAGS and out_flags.dtype == torch.int32)
         stream = self._raw_stream(queries.device)
         L.check(self._lib.rdx_search_async(self._h, ctypes.c_void_p(queries.data_ptr()), nq, int(k), None,
                                            ctypes.c_void_p(out_score.data_ptr()), ctypes.c_void_p(out_row.data_ptr()),
-                                           ctypes.c_void_p(out_count.data_ptr()), ctypes.c_void_p(stream)))
+                                           ctypes.c_void_p(out_count.data_ptr()),
+                                           ctypes.c_void_p(out_flags.data_ptr()) if out_flags is not None else None,
+                                           ctypes.c_void_p(stream)))
 
     def search_wait(self) -> bool:
         """-> True when fallback passes rewrote results after the asynchronous search's kernels (consumers must be re-run)"""

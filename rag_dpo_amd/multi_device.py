@@ -299,17 +299,9 @@ class MultiDeviceIndex:
             return parts[0]
         if k == 0:
             return parts[0][0], parts[0][1], np.zeros(nq, np.int32)
-        # the merge kernel ranks at most MERGE_MAX = 4096 candidates per query: merge in rounds when D * k exceeds that
-        group = max(2, 4096 // int(k))
-        while len(parts) > 1:
-            nxt = []
-            for a in range(0, len(parts), group):
-                g = parts[a:a + group]
-                nxt.append(g[0] if len(g) == 1 else
-                           self._merge(np.stack([p[0] for p in g]), np.stack([p[1] for p in g]), np.stack([p[2] for p in g]),
-                                       int(k), self.device))
-            parts = nxt
-        return parts[0]
+        # ONE merge call whatever D and k: the library folds the parts pairwise when D * k exceeds what its merge kernel ranks at once
+        return self._merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), np.stack([p[2] for p in parts]),
+                           int(k), self.device)
 
     def last_stats(self) -> dict:
         """per-shard stats of the last search, plus the sums of the additive counters"""

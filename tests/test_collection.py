@@ -291,6 +291,37 @@ def test_persist_killed_before_or_after_its_commit_point(tmp_path):
     assert sorted(os.listdir(d)) == sorted(after_files)           # journal1 was NOT replayed on top of snapshot 2, and is gone
 
 
+def test_failed_snapshot_leaves_the_store_on_its_old_generation(tmp_path, monkeypatch):
+    """persist() that fails while writing generation g+1 (disk full in np.save): the object must stay on generation g, so that
+    the writes acknowledged afterwards go to the journal the header names and are there at the next open"""
+    import os
+    cl = _open(tmp_path)
+    col = cl.create_collection("rag_dpo_chunks", metadata={"hnsw:space": "cosine"})
+    emb = synth.make_corpus(40, 64)
+    col.add(ids=[f"a{i}" for i in range(10)], embeddings=emb[:10].tolist(), documents=[f"d{i}" for i in range(10)])
+    cl.persist()                                                  # generation 1
+    col.add(ids=["b0"], embeddings=emb[10:11].tolist())
+    gen = col._gen
+
+    def full(*a, **kw):
+        raise OSError(28, "No space left on device")
+    monkeypatch.setattr(np, "save", full)
+    with pytest.raises(OSError):
+        cl.persist()
+    monkeypatch.undo()
+    assert col._gen == gen
+    assert not [fn for fn in os.listdir(col._dir) if fn.startswith(f"snap{gen + 1}.") or fn.endswith(".tmp")]
+    col.add(ids=["c0", "c1"], embeddings=emb[11:13].tolist(), documents=["x", "y"])   # acknowledged after the failure
+    col.delete(ids=["a4"])
+    want = _state(col)
+    got = _state(_open(tmp_path).get_collection("rag_dpo_chunks"))
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and (got[3] == want[3]).all()
+    assert "c1" in got[0] and "a4" not in got[0]
+    cl.persist()                                                  # and a later snapshot succeeds
+    got = _state(_open(tmp_path).get_collection("rag_dpo_chunks"))
+    assert got[0] == want[0] and (got[3] == want[3]).all()
+
+
 def test_reload_keeps_stored_vectors_bit_for_bit(tmp_path):
     """snapshot rows are reloaded verbatim (engine.add_stored), not normalised a second time: distances before persist
     and after reopen are the same floats (the reference indexes in one process and serves from another)"""

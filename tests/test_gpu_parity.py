@@ -112,6 +112,7 @@ def test_search_in_two_halves(eng, oracle):
     qd = torch.from_numpy(q).cuda()
     s = torch.empty((130, 50), dtype=torch.float32, device="cuda"); r = torch.empty((130, 50), dtype=torch.int64, device="cuda")
     c = torch.empty((130,), dtype=torch.int32, device="cuda")
+    f = torch.full((4,), 7, dtype=torch.int32, device="cuda")
 
     def check():
         torch.cuda.synchronize()
@@ -126,6 +127,32 @@ def test_search_in_two_halves(eng, oracle):
     ix.search_device_async(qd, 50, s, r, c)
     assert ix.search_wait() is True
     check()
+    # the flags word (include/rdx.h): 0 behind a complete first pass; 1 while the partial is incomplete — what a consumer enqueued
+    # behind the search (the all-gather) sees — and 0 again once the wait has run the fallback passes
+    ix.set_option("cand_cap", 0)
+    ix.search_device_async(qd, 50, s, r, c, f)
+    seen = f.clone()                                       # stream-ordered behind the search's last kernel, before the host half
+    assert ix.search_wait() is False
+    assert seen.tolist() == [0, 0, 0, 0] and f.tolist() == [0, 0, 0, 0]
+    ix.set_option("cand_cap", 8)
+    s.zero_(); r.zero_(); c.zero_()
+    q2 = qd.clone()
+    ix.search_device_async(q2, 50, s, r, c, f)
+    seen = f.clone()
+    q2.fill_(float("nan"))                                 # `queries` belongs to the caller again once the search is enqueued:
+    assert ix.search_wait() is True                        #   the fallback passes work from the index's own normalised copy
+    assert seen.tolist() == [1, 0, 0, 0] and f.tolist() == [0, 0, 0, 0]
+    check()
+    ix.set_option("retry", 0)                              # straight to the exact scan of the overflowed queries: same contract
+    s.zero_(); r.zero_(); c.zero_()
+    q2 = qd.clone()
+    ix.search_device_async(q2, 50, s, r, c, f)
+    seen = f.clone()
+    q2.fill_(float("nan"))
+    assert ix.search_wait() is True
+    assert seen.tolist() == [1, 0, 0, 0] and f.tolist() == [0, 0, 0, 0]
+    check()
+    ix.set_option("retry", 1)
     s.zero_(); r.zero_(); c.zero_()
     ix.search_device_async(qd, 50, s, r, c)                # never waited for: the next call on the index completes it first
     gs, gr, gc = ix.search(q[:7], 50)
@@ -341,6 +368,125 @@ def test_merge_parity(eng, oracle):
     for b in range(B):
         np.testing.assert_array_equal(gr[b, :gc[b]], er[b, :ec[b]])
         np.testing.assert_array_equal(gs[b, :gc[b]], es[b, :ec[b]])
+
+
+@pytest.mark.parametrize("P,k", [(2, 2500), (3, 4096), (8, 700), (64, 65)])
+def test_merge_more_candidates_than_one_launch(eng, oracle, P, k):
+    """n_parts * k > 4096: rdx_merge_topk folds the parts pairwise (k_merge_pair) — same lists as the oracle's merge"""
+    rng = np.random.default_rng(P * 10000 + k)
+    B = 6
+    ps = np.sort(rng.standard_normal((P, B, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    ps[-1] = ps[0]                                  # equal scores across parts -> tie by row id
+    pr = np.empty((P, B, k), dtype=np.int64)
+    for b in range(B):
+        rows = rng.permutation(P * k).reshape(P, k)
+        for p in range(P):
+            pr[p, b] = rows[p]                      # no row in two parts
+    # every list sorted (score desc, row asc), as a shard returns it
+    for p in range(P):
+        for b in range(B):
+            o = np.lexsort((pr[p, b], -ps[p, b].astype(np.float64)))
+            ps[p, b], pr[p, b] = ps[p, b][o], pr[p, b][o]
+    pc = rng.integers(0, k + 1, size=(P, B)).astype(np.int32)
+    pc[0, 0] = k; pc[1, 0] = k; pc[0, 1] = 0
+    es, er, ec = oracle.merge_topk(ps, pr, pc, k)
+    gs, gr, gc = eng.merge_topk(ps, pr, pc, k)
+    np.testing.assert_array_equal(gc, ec)
+    for b in range(B):
+        np.testing.assert_array_equal(gr[b, :gc[b]], er[b, :ec[b]])
+        np.testing.assert_array_equal(gs[b, :gc[b]], es[b, :ec[b]])
+        assert (gr[b, gc[b]:] == -1).all()
+
+
+def test_packed_merge_and_signal(eng, oracle):
+    """rdx_merge_topk_packed over the all-gather layout (rows | scores | counts | flags per part) + rdx_signal: the merged lists
+    equal the oracle's merge, and the host reads the OR of the parts' flags words from the signal (same answer wherever it runs)"""
+    import ctypes
+    import torch
+    from rag_dpo_amd import _lib as L
+    from rag_dpo_amd.sharded import ShardedSearcher, packed_bytes
+    lib = L.load()
+    rng = np.random.default_rng(12)
+    P, B, k = 5, 33, 7
+    ps = np.sort(rng.standard_normal((P, B, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    pr = rng.permutation(P * B * k).reshape(P, B, k).astype(np.int64)
+    pc = rng.integers(0, k + 1, size=(P, B)).astype(np.int32)
+    es, er, ec = oracle.merge_topk(ps, pr, pc, k)
+    stride = (packed_bytes(B, k) + 15) // 16 * 16
+    buf = torch.zeros(P * stride, dtype=torch.uint8, device="cuda")
+    parts = [ShardedSearcher.views(buf[p * stride:(p + 1) * stride], B, k) for p in range(P)]
+    for p in range(P):
+        parts[p][0].copy_(torch.from_numpy(ps[p])); parts[p][1].copy_(torch.from_numpy(pr[p])); parts[p][2].copy_(torch.from_numpy(pc[p]))
+    os_ = torch.empty((B, k), dtype=torch.float32, device="cuda"); or_ = torch.empty((B, k), dtype=torch.int64, device="cuda")
+    oc = torch.empty((B,), dtype=torch.int32, device="cuda")
+    sig = ctypes.c_void_p()
+    L.check(lib.rdx_signal_create(0, ctypes.byref(sig)))
+    v = ctypes.c_int32(-1)
+    with pytest.raises(L.RdxError):
+        L.check(lib.rdx_signal_wait(sig, None, ctypes.byref(v)))          # no merge was given the signal yet
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for flagged in ([], [3], [0, 4], []):
+        for p in range(P):
+            parts[p][3][0] = 1 if p in flagged else 0
+        L.check(lib.rdx_merge_topk_packed(0, ptr(buf), stride, P, B, k, ptr(os_), ptr(or_), ptr(oc), sig, stream))
+        L.check(lib.rdx_signal_wait(sig, stream, ctypes.byref(v)))
+        assert v.value == (1 if flagged else 0)
+        torch.cuda.synchronize()
+        gc = oc.cpu().numpy()
+        np.testing.assert_array_equal(gc, ec)
+        for b in range(B):
+            np.testing.assert_array_equal(or_.cpu().numpy()[b, :gc[b]], er[b, :ec[b]])
+            np.testing.assert_array_equal(os_.cpu().numpy()[b, :gc[b]], es[b, :ec[b]])
+    with pytest.raises(ValueError):                                       # a stride that does not cover the flags word
+        L.check(lib.rdx_merge_topk_packed(0, ptr(buf), (B * k * 12 + B * 4 + 15) // 16 * 16 - 16, P, B, k, ptr(os_), ptr(or_), ptr(oc), None, stream))
+    L.check(lib.rdx_signal_destroy(sig))
+
+
+def test_sharded_searcher_world1_flags_path():
+    """ShardedSearcher on the product backend with always_exchange (no process group here: the gather of the one part is a
+    copy): a search whose segments overflow repeats the exchange once, told so by the merged flags word; a clean one does not"""
+    import torch
+    from rag_dpo_amd.sharded import HipShard, ShardedSearcher
+    from oracle import oracle as O
+    corpus = synth.make_corpus(40_000, 1024)
+    q = synth.make_queries(130, 1024, corpus)
+    es, er, ec = O.cosine_topk(O.normalize_rows(corpus), q, 50)
+    sh = HipShard(1024, 0, row_offset=1000)
+    sh.add(corpus)
+    sh.index.set_option("force_fast", 1)
+
+    ss = ShardedSearcher(sh, always_exchange=True)
+    qd = torch.from_numpy(q).cuda()
+    for cap, want in ((0, 1), (8, 2), (0, 1)):
+        sh.index.set_option("cand_cap", cap)
+        n0 = ss.exchanges
+        qq = qd.clone()
+        ss.search_begin(qq, 50)
+        qq.fill_(float("nan"))             # stream-ordered behind the search: allowed (include/rdx.h "Lifetimes")
+        s, r, c = ss.search_end()
+        torch.cuda.synchronize()
+        assert ss.exchanges - n0 == want, (cap, ss.exchanges - n0)
+        np.testing.assert_array_equal(r.cpu().numpy(), np.where(er >= 0, er + 1000, -1))
+        np.testing.assert_array_equal(s.cpu().numpy(), es); np.testing.assert_array_equal(c.cpu().numpy(), ec)
+    sh.close()
+
+
+@pytest.mark.parametrize("b", [1, 4])
+def test_reference_shape_on_the_default_path(eng, oracle, b):
+    """BASELINE config 1 at the reference's REAL shape on the path the library picks by itself: 16,919 rows (README.en.md:300-305),
+    one query vector per call or the <= 4 reformulations of one question, n_results = 50 (reference src/rag/retriever.py:202,
+    215-220, 342) — the exact scan K5 — without and with a `where` bitmap"""
+    corpus = synth.make_corpus(16_919, 1024)
+    q = synth.make_queries(b, 1024, corpus)
+    ix = _index(eng, corpus)
+    st = _check(oracle, ix, corpus, q, 50, expect_path=1)
+    assert st["exact_queries"] == b
+    allow = (np.arange(16_919) % 4 == 1) | (np.random.default_rng(b).random(16_919) < 0.05)   # a chunk_nature-like filter
+    _check(oracle, ix, corpus, q, 50, allow, expect_path=1)
+    few = np.zeros(16_919, dtype=bool); few[[5, 16_918, 4000]] = True                          # fewer rows pass than n_results
+    _check(oracle, ix, corpus, q, 50, few, expect_path=1)
+    ix.close()
 
 
 @pytest.mark.parametrize("k", [256, 300])

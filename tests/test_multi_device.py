@@ -1,5 +1,5 @@
 """rag_dpo_amd.multi_device: the rows of ONE collection over several devices in ONE process. CPU: the orchestration
-(water-filled placement, row-id maps, per-shard bitmaps, compaction, rollback, merge in rounds) with TEST-ONLY oracle
+(water-filled placement, row-id maps, per-shard bitmaps, compaction, rollback, one merge whatever D x k) with TEST-ONLY oracle
 shards standing in for the per-device HipIndex — every result must equal a single oracle engine holding all rows.
 GPU (one card): three HipIndex shards on cuda:0 must equal one HipIndex bit for bit."""
 import numpy as np
@@ -63,7 +63,7 @@ def test_multi_device_equals_single_engine(n_dev, oracle):
     sizes = [len(s) for s in md._shards]
     assert max(sizes) - min(sizes) <= 1, sizes                # water-filling keeps the shards level
     q = synth.make_queries(9, dim, corpus)
-    for k in (1, 10, 50, 700):                                # 700 * 8 > 4096: merged in rounds
+    for k in (1, 10, 50, 700, 2500):                          # 700 * 8, 2500 * 2 > 4096: more candidates than one merge launch ranks
         same(md.search(q, k), one.search(q, k))
     same([md.get(np.array([5, 2999, 0, 1234]))], [one.get(np.array([5, 2999, 0, 1234]))])
     # where bitmaps: collection bitmap -> per-shard bitmaps; resident form too
@@ -144,6 +144,7 @@ def test_three_shards_on_one_gpu_equal_one_index(oracle):
     for ix in (one, md):
         ix.set_option("force_fast", 0); ix.set_option("force_exact", 1)
     same(md.search(q[:5], 300), one.search(q[:5], 300))       # exact path through the id map as well
+    same(md.search(q[:5], 2100), one.search(q[:5], 2100))     # 3 x 2100 candidates per query: the library folds the parts pairwise
     keep = np.flatnonzero(rng.random(n) < 0.5)
     md.compact(keep); one.compact(keep)
     for ix in (one, md):

@@ -28,6 +28,7 @@ class OracleShard:
         self.rows = corpus_hat
         self.off = row_offset
         self.device = torch.device("cpu")
+        self.flag, self.flag_reads = False, 0
 
     def search(self, queries, k, out_score, out_row, out_count):
         from oracle import oracle as O
@@ -43,21 +44,31 @@ class OracleShard:
         s, r, c = O.merge_topk(np.stack([p[0].numpy() for p in parts]), np.stack([p[1].numpy() for p in parts]),
                                np.stack([p[2].numpy() for p in parts]), k)
         out_score.copy_(torch.from_numpy(s)); out_row.copy_(torch.from_numpy(r)); out_count.copy_(torch.from_numpy(c))
+        # what k_merge's first block publishes through the rdx_signal: the OR of the gathered partials' flags words
+        self.flag = any(int(p[3][0]) != 0 for p in parts)
+
+    def merge_flag(self):
+        self.flag_reads += 1
+        return self.flag
 
 
 class DeferredOracleShard(OracleShard):
     """test double of the ASYNCHRONOUS form (HipShard.search_async / search_wait): the first pass leaves the partial of the
     queries in `late` empty, as an overflowed query's is until its fallback pass has run; search_wait() completes them and
-    says so on the ranks where that happened — the exchange must then be repeated on EVERY rank"""
+    says so on the ranks where that happened — the exchange must then be repeated on EVERY rank. As librdx does it: the
+    search's last kernel sets flags[0] of the packed partial while the partial is incomplete, the host half clears it."""
 
     def __init__(self, corpus_hat, row_offset, late):
         super().__init__(corpus_hat, row_offset)
         self.late, self.pending, self.waits = late, None, 0
 
-    def search_async(self, queries, k, out_score, out_row, out_count):
+    def search_async(self, queries, k, out_score, out_row, out_count, out_flags):
         OracleShard.search(self, queries, k, out_score, out_row, out_count)
         self.pending = None
+        self.flags = out_flags
+        out_flags.zero_()
         if len(self.late):
+            out_flags[0] = 1
             self.pending = (out_score[self.late].clone(), out_row[self.late].clone(), out_count[self.late].clone(), out_score, out_row, out_count)
             out_score[self.late] = float("-inf"); out_row[self.late] = -1; out_count[self.late] = 0
         return True
@@ -68,6 +79,7 @@ class DeferredOracleShard(OracleShard):
             return False
         s, r, c, out_score, out_row, out_count = self.pending
         out_score[self.late] = s; out_row[self.late] = r; out_count[self.late] = c
+        self.flags[0] = 0
         self.pending = None
         return True
 
@@ -106,10 +118,24 @@ def _worker(rank, world, port, n, dim, b, k, out_dir):
         pass
     # asynchronous form: rank 1's first pass is incomplete for queries 2 and 5 (every other rank's is complete) — all ranks
     # must repeat the exchange and end with the same, complete result; with nothing late nobody repeats it
-    for late in ([2, 5], []):
-        sh = DeferredOracleShard(corpus[lo:hi], lo, late if rank == 1 else [])
-        s3, r3, c3 = ShardedSearcher(sh).search(q, k)
-        assert sh.waits == 1
+    # The decision travels in the flags word of the packed partials (no collective besides the all-gather): every rank
+    # reads the same OR from the merge and repeats the exchange exactly once when it is set.
+    real_all_reduce = dist.all_reduce
+    def no_all_reduce(*a, **kw):
+        raise AssertionError("a sharded step must not run an all-reduce")
+    for late_rank, late in ((1, [2, 5]), (world - 1, [0]), (1, [])):
+        sh = DeferredOracleShard(corpus[lo:hi], lo, late if rank == late_rank else [])
+        ss3 = ShardedSearcher(sh)
+        dist.all_reduce = no_all_reduce
+        try:
+            qq = q.clone()
+            ss3.search_begin(qq, k)
+            qq.fill_(float("nan"))        # the caller's buffer is the searcher's to keep alive, not the caller's to preserve
+            s3, r3, c3 = ss3.search_end()
+        finally:
+            dist.all_reduce = real_all_reduce
+        assert sh.waits == 1 and sh.flag_reads == 1
+        assert ss3.exchanges == (2 if late else 1), (rank, late, ss3.exchanges)
         assert torch.equal(r, r3) and torch.equal(s, s3) and torch.equal(c, c3), (rank, late)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), r=r.numpy(), c=c.numpy())
     dist.barrier()
