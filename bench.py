@@ -199,7 +199,9 @@ def main():
                     help="N=1: initialise torch.distributed (nccl = RCCL) anyway and run the all-gather + merge with world 1 "
                          "(the exchange path on the real backend when only one GPU is there)")
     ap.add_argument("--check-merged", action="store_true",
-                    help="N>1: rank 0 also builds the WHOLE corpus in one index and checks that the merged result is bit-identical")
+                    help="N>1: rank 0 also builds the WHOLE corpus in one index and checks that the merged result is bit-identical "
+                         "(the default cross-rank exactness leg needs no second copy of the corpus)")
+    ap.add_argument("--no-check", action="store_true", help="N>1 / --force-dist: skip the cross-rank exactness leg and the step breakdown")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -253,6 +255,10 @@ def main():
     log(f"[rank {rank}] shard rows [{lo}, {hi}) resident in {time.time() - t_build:.1f}s")
     searcher = ShardedSearcher(shard, host_staged=rehearsal, always_exchange=args.force_dist)
     queries, planted = synth.torch_queries(B, dim, device, total_rows=rows, return_planted=True)   # 10 % planted (§8d)
+    # ONE query batch for all ranks: rank 0's, broadcast once, outside the timed region (the rank that took the
+    # request hands it to the others). Nothing rests on every rank's generator producing the same bits.
+    if world > 1 or args.force_dist:
+        searcher.broadcast_queries(queries, 0)
     # HIP events on the stream the kernels run on: 2 = around the dominant kernel (the main scan) only, which is what the
     # timed region carries; --profile-all records every kernel boundary (7 events per search: visible in small configs)
     # --timer stamps (profile = 3): no events at all, the dominant kernel stamps its own first-workgroup start and last-workgroup
@@ -351,6 +357,66 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- N > 1 (and the one-rank RCCL group of --force-dist): the line proves itself ---------------------------------
+    # (1) cross-rank exactness, no oracle over 10 M rows needed: for 32 queries every rank ALSO answers from its shard with the
+    #     exact full scan K5 (fp32, no MFMA, no thresholds; oracle-checked at small N by the test suite), those partials go
+    #     through the SAME all-gather + merge, and the merged lists must equal the MFMA path's merged lists bit for bit: no
+    #     better row exists in any shard, and the exchange + merge handled both identically. (2) every rank's merged output
+    #     is checksummed and the checksums compared: all ranks hold the same answer. (3) what RCCL ran on. (4) where a step's
+    #     time goes on rank 0 (events around the pieces, in a separate short leg: never inside the timed region).
+    dist_check, rccl_info, step_breakdown = None, None, None
+    if (world > 1 or args.force_dist):
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "device_index": local_rank, "name": props.name, "gcnArch": getattr(props, "gcnArchName", "?").split(":")[0]}
+        infos = [None] * world
+        dist.all_gather_object(infos, mine)
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if not rehearsal else None
+        except Exception:
+            ver = None
+        rccl_info = {"world": world, "backend": dist.get_backend(), "rccl_version": ver, "devices": infos,
+                     "collectives_per_step": "1 all_gather_into_tensor of the packed partials (rows|scores|counts|flags), nothing else",
+                     "queries": "rank 0's batch, broadcast once before the timed region"}
+        if not args.no_check:
+            nchk = min(B, 32)
+            qs = queries[:nchk].contiguous()
+            m_s, m_r, m_c = [t.clone() for t in searcher.search(qs, k)]
+            full_s, full_r, full_c = [t.clone() for t in searcher.search(queries, k)]     # the whole batch, for the checksum
+            shard.index.set_option("force_exact", 1)
+            x_s, x_r, x_c = [t.clone() for t in searcher.search(qs, k)]
+            shard.index.set_option("force_exact", 0)
+            torch.cuda.synchronize(device)
+            exact_equal = bool((x_r == m_r).all() and (x_s == m_s).all() and (x_c == m_c).all())
+            prefix_equal = bool((full_r[:nchk] == m_r).all() and (full_s[:nchk] == m_s).all())   # a query's answer does not depend on its batch
+            # checksum of everything this rank would hand to a caller: rows, score BITS, counts (wrapping int64 sums + a weighted one)
+            w = torch.arange(1, full_r.numel() + 1, device=full_r.device, dtype=torch.int64)
+            bits = full_s.view(torch.int32).to(torch.int64)
+            ck = torch.stack([full_r.sum(), (full_r.flatten() * w).sum(), bits.sum(), (bits.flatten() * w).sum(),
+                              full_c.to(torch.int64).sum(), torch.tensor(int(exact_equal and prefix_equal), device=full_r.device)])
+            ck_h = ck.cpu() if rehearsal else ck
+            allck = torch.empty((world, ck.numel()), dtype=torch.int64, device=ck_h.device)
+            dist.all_gather_into_tensor(allck, ck_h)
+            allck = allck.cpu()
+            dist_check = {"queries_exact_leg": nchk,
+                          "per_shard_exact_scan_merged_equals_mfma_merged": bool(allck[:, 5].all().item()),
+                          "merged_identical_on_all_ranks": bool((allck[:, :5] == allck[0, :5]).all().item()),
+                          "checksum_rank0": [int(v) for v in allck[0, :5]],
+                          "exchanges_per_search": "1 (a second one only when the merged flags word says a rank re-ran overflowed queries)"}
+            # step breakdown on rank 0: search kernels / all-gather / merge, events on the stream, min(steps, 10) extra steps
+            searcher.time_events = True
+            nb = max(3, min(args.steps, 10))
+            ex0 = searcher.exchanges
+            for _ in range(nb):
+                searcher.search(queries, k)
+            barrier()
+            bd = searcher.breakdown(last=nb)
+            searcher.time_events = False
+            if bd is not None:
+                step_breakdown = {"steps": nb, "scan_ms": round(bd[0], 4), "exchange_ms": round(bd[1], 4), "merge_ms": round(bd[2], 4),
+                                  "exchanges": searcher.exchanges - ex0,
+                                  "note": "rank 0, torch events on the search's stream: everything librdx enqueues for the shard's search "
+                                          "(K1 .. k_finish) | all_gather_into_tensor | rdx_merge_topk_packed; a separate leg after the timed region"}
 
     merged_ok = None
     if args.check_merged and world > 1:
@@ -458,7 +524,7 @@ def main():
         # `value`: the H2D copy of the fp32 query batch from pinned host memory, and the whole search called with HOST
         # pointers (rdx_search RDX_HOST: pageable numpy in, H2D, search, D2H of the k results, numpy out)
         pcie = None
-        if world == 1 and not encode:
+        if world == 1:
             try:
                 hq = queries.cpu().pin_memory()
                 dq = torch.empty_like(queries)
@@ -502,7 +568,7 @@ def main():
                        "synthetic_inputs": "SURVEY.md §8d: N(0,1) rows with 1 % exact duplicate rows, N(0,1) queries with 10 % planted next to a row",
                        "parallelism": f"row-shard x{world} + all-gather merge"},
             "roofline": roof, "roofline_small_batch": small, "pcie_inclusive": pcie, "cpu_baseline": cpu, "recall_at_10": rec,
-            "merged_equals_single_index": merged_ok,
+            "merged_equals_single_index": merged_ok, "rccl": rccl_info, "distributed_check": dist_check, "step_breakdown": step_breakdown,
             "encode": ({"model": "XLM-R-large (BGE-M3 architecture), random-init fp16, hashing tokenizer", "texts_per_step": B,
                         "avg_ms": round(sum(a.elapsed_time(b) for a, b in enc_ev) / max(1, len(enc_ev)), 3),
                         "pipelined_with_search": bool(serial is not None), "serial_leg": serial,

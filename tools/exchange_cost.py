@@ -12,7 +12,7 @@ nq, k = 1024, 10
 sh = HipShard(1024, 0)
 ss = ShardedSearcher(sh, always_exchange=True)
 per_pad, local, allb, out = ss._buffers(nq, k)
-s, r, c = ss.views(local, nq, k); c.fill_(k); r.copy_(torch.arange(nq * k, device=dev).view(nq, k)); s.copy_(torch.rand(nq, k, device=dev).sort(dim=1, descending=True).values)
+s, r, c, _f = ss.views(local, nq, k); c.fill_(k); r.copy_(torch.arange(nq * k, device=dev).view(nq, k)); s.copy_(torch.rand(nq, k, device=dev).sort(dim=1, descending=True).values)
 def run(n, what):
     torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter(); e0.record()
