@@ -395,9 +395,9 @@ def main():
             ck = torch.stack([full_r.sum(), (full_r.flatten() * w).sum(), bits.sum(), (bits.flatten() * w).sum(),
                               full_c.to(torch.int64).sum(), torch.tensor(int(exact_equal and prefix_equal), device=full_r.device)])
             ck_h = ck.cpu() if rehearsal else ck
-            allck = torch.empty((world, ck.numel()), dtype=torch.int64, device=ck_h.device)
+            allck = torch.empty(world * ck.numel(), dtype=torch.int64, device=ck_h.device)   # (flat: gloo refuses a 2-D output)
             dist.all_gather_into_tensor(allck, ck_h)
-            allck = allck.cpu()
+            allck = allck.cpu().view(world, ck.numel())
             dist_check = {"queries_exact_leg": nchk,
                           "per_shard_exact_scan_merged_equals_mfma_merged": bool(allck[:, 5].all().item()),
                           "merged_identical_on_all_ranks": bool((allck[:, :5] == allck[0, :5]).all().item()),

@@ -1,0 +1,304 @@
+"""Build-time check of the scan kernels' hand-counted memory waits, on the ISA the compiler actually emitted.
+
+The scan kernel (csrc/scan_kernel.hpp) issues its corpus loads as inline asm `global_load_dwordx4` and retires them with
+counted `s_waitcnt vmcnt(N)`: the compiler does not know that the destination registers of such a load are "not there yet"
+between the two. Whatever it places in that window that READS or WRITES those registers — a copy around a branch, a reused
+register, a spill — is silently wrong (stale fragments, or a late write-back into a register that now holds something else).
+"The kernels must not spill" (build.py) catches one way of getting there; this module checks the property itself:
+
+    for every path through a k_scan kernel, no instruction between an asm global_load_dwordx4 and the s_waitcnt that retires
+    it touches that load's destination VGPRs.
+
+Model (gfx950 = gfx9 family): every vector-memory instruction (global/buffer/flat/scratch load, store, atomic, LDS-DMA) takes
+one vmcnt slot in issue order and the slots retire in order; `s_waitcnt vmcnt(N)` returns when at most N are outstanding, i.e.
+all but the N youngest have retired. A forward dataflow over the function's control-flow graph carries, for every asm load in
+flight, the fewest operations issued after it on any path (check_function): loops and rare paths included.
+
+    python -m rag_dpo_amd.isa_check file.s [more.s]      # developer: check ISA listings (hipcc --cuda-device-only -S)
+"""
+from __future__ import annotations
+
+import re
+import sys
+from typing import Dict, List, Tuple
+
+VM_PREFIXES = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "flat_load",
+               "flat_store", "flat_atomic", "scratch_load", "scratch_store", "tbuffer_load", "tbuffer_store")
+_V1 = re.compile(r"\bv(\d+)\b")
+_VR = re.compile(r"\bv\[(\d+):(\d+)\]")
+_LABEL = re.compile(r"^(\.L[A-Za-z0-9_$.]+):")
+_VMCNT = re.compile(r"vmcnt\((\d+)\)")
+
+
+def vgprs(operands: str) -> frozenset:
+    out = set(int(m.group(1)) for m in _V1.finditer(operands))
+    for m in _VR.finditer(operands):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return frozenset(out)
+
+
+class Ins:
+    __slots__ = ("line", "text", "op", "regs", "asm", "vm", "wait", "target", "kind", "dst")
+
+    def __init__(self, line: int, text: str, in_asm: bool):
+        self.line, self.text, self.asm = line, text, in_asm
+        parts = text.split(None, 1)
+        self.op = parts[0]
+        ops = parts[1] if len(parts) > 1 else ""
+        ops = ops.split(";")[0]
+        self.regs = vgprs(ops)
+        self.vm = self.op.startswith(VM_PREFIXES)
+        self.wait = None
+        if self.op == "s_waitcnt":
+            m = _VMCNT.search(ops)
+            self.wait = int(m.group(1)) if m else None
+            if m is None and re.fullmatch(r"\s*(0x[0-9a-fA-F]+|\d+)\s*", ops):   # raw immediate: vmcnt = bits [3:0] | [15:14] << 4
+                imm = int(ops.strip(), 0)
+                self.wait = (imm & 0xF) | (((imm >> 14) & 0x3) << 4)
+        self.target = None
+        self.kind = "plain"
+        if self.op == "s_branch":
+            self.kind, self.target = "jump", ops.strip()
+        elif self.op.startswith("s_cbranch"):
+            self.kind, self.target = "cond", ops.strip().split(",")[-1].strip()
+        elif self.op in ("s_endpgm", "s_setpc_b64"):
+            self.kind = "end"
+        # an in-flight asm load: destination = first operand
+        self.dst = None
+        if in_asm and self.op.startswith("global_load_dwordx4"):
+            first = ops.split(",")[0]
+            self.dst = vgprs(first)
+
+
+def split_functions(text: str) -> Dict[str, List[Tuple[int, str]]]:
+    """{symbol: [(line number, line)]} for every function body in an AMDGPU assembly listing"""
+    out, cur, name = {}, None, None
+    for i, ln in enumerate(text.splitlines(), 1):
+        m = re.match(r"^([A-Za-z_][A-Za-z0-9_$.]*):\s*(;.*)?$", ln)
+        if m and not ln.startswith(".L"):
+            name, cur = m.group(1), []
+            out[name] = cur
+            continue
+        if cur is not None:
+            if ln.startswith("\t.section") or ln.startswith(".Lfunc_end"):
+                cur, name = None, None
+                continue
+            cur.append((i, ln))
+    return out
+
+
+def build_cfg(lines: List[Tuple[int, str]]):
+    """-> (blocks: list of [Ins], label -> block index)"""
+    blocks, labels, cur, in_asm = [[]], {}, None, False
+    for no, ln in lines:
+        s = ln.strip()
+        if not s:
+            continue
+        m = _LABEL.match(s)
+        if m:
+            if blocks[-1]:
+                blocks.append([])
+            labels[m.group(1)] = len(blocks) - 1
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if s.startswith(";") or s.startswith(".") or s.startswith("//"):
+            continue
+        ins = Ins(no, s, in_asm)
+        blocks[-1].append(ins)
+        if ins.kind != "plain":
+            blocks.append([])
+    # labels bound to an empty trailing block index are fine: successor resolution skips empties by falling through
+    return blocks, labels
+
+
+def _dataflow(name: str, blocks, labels, optimistic: bool, on_touch):
+    """Forward dataflow to a fixed point. State at a program point: {asm load in flight: number of vector-memory operations
+    issued after it}. A load with y younger operations retires at `s_waitcnt vmcnt(N)` iff y >= N. Paths are joined by the
+    union of the loads and the MINIMUM of the counts (conservative: a load is considered in flight as long as it is on the path
+    with the least traffic behind it) or, `optimistic`, the MAXIMUM (a load counts as retired as soon as it is on some path)."""
+    pick = max if optimistic else min
+    state_in: List[dict] = [None] * len(blocks)
+    state_in[0] = {}
+    work, passes, max_fl = [0], 0, 0
+
+    def merge(bi: int, st: dict):
+        if bi >= len(blocks):
+            return
+        cur = state_in[bi]
+        if cur is None:
+            state_in[bi] = dict(st)
+            work.append(bi)
+            return
+        changed = False
+        for ld, y in st.items():
+            if ld not in cur:
+                cur[ld] = y
+                changed = True
+            elif pick(cur[ld], y) != cur[ld]:
+                cur[ld] = pick(cur[ld], y)
+                changed = True
+        if changed:
+            work.append(bi)
+
+    while work:
+        bi = work.pop()
+        passes += 1
+        if passes > 400000:
+            raise RuntimeError(f"{name}: the dataflow does not settle")
+        st = dict(state_in[bi])
+        ended = False
+        for ins in blocks[bi]:
+            if ins.regs and st:
+                for ld in st:
+                    if ld is not ins and (ld.dst & ins.regs):
+                        on_touch(ins, ld)
+            if ins.wait is not None and st:
+                st = {ld: y for ld, y in st.items() if y < ins.wait}
+            if ins.vm:
+                st = {ld: min(y + 1, 4096) for ld, y in st.items()}
+                if ins.dst:
+                    st[ins] = 0
+                max_fl = max(max_fl, len(st))
+            if ins.kind == "end":
+                ended = True
+            elif ins.kind == "jump":
+                merge(labels[ins.target], st)
+                ended = True
+            elif ins.kind == "cond":
+                merge(labels[ins.target], st)
+        if not ended:
+            merge(bi + 1, st)
+    return passes, max_fl
+
+
+def _is_consumer(ins: "Ins", regs) -> bool:
+    """the one thing the source does with a landed fragment: an MFMA reads it (never writes it)"""
+    if not ins.op.startswith("v_mfma"):
+        return False
+    ops = ins.text.split(None, 1)[1]
+    return not (vgprs(ops.split(",")[0]) & regs)
+
+
+def check_function(name: str, lines: List[Tuple[int, str]]):
+    """-> (hazards, stats). Two passes over the control-flow graph (see _dataflow):
+
+    (A) conservative window — between an asm load and the LATEST point at which it can retire, nothing but the source's own uses
+        may touch its destination registers: MFMA source reads (the consumers, which the source orders behind the counted wait
+        through the wait statement's "+v" operands) and the asm loads themselves. Anything else — v_mov / v_accvgpr copies,
+        scratch stores, a register reused for another value, an MFMA writing it — is the compiler handling a value it believes
+        is there: refused. (The window is a superset: the two waves of a SIMD issue their DMA at different places behind
+        wave-uniform branches, and a path-insensitive join keeps the shortest count; consumers inside it are expected.)
+    (B) optimistic window — a consumer or a second load that touches the registers before the load can have retired on ANY path
+        (maximum count at every join) is a wrong wait count, whatever the compiler did: refused."""
+    blocks, labels = build_cfg(lines)
+    hazards, seen_h = [], set()
+    n_loads = sum(1 for b in blocks for i in b if i.dst)
+
+    def report(kind, ins, ld):
+        key = (kind, ins.line, ld.line)
+        if key not in seen_h:
+            seen_h.add(key)
+            hazards.append({"kind": kind, "line": ins.line, "text": ins.text, "load_line": ld.line, "load_text": ld.text,
+                            "regs": sorted(ld.dst & ins.regs)})
+
+    def touch_a(ins, ld):
+        if ins.dst is not None or _is_consumer(ins, ld.dst & ins.regs):
+            return
+        report("foreign instruction touches an in-flight fragment", ins, ld)
+
+    def touch_b(ins, ld):
+        report("fragment used before its load can have retired", ins, ld)
+
+    pa, fl = _dataflow(name, blocks, labels, False, touch_a)
+    pb, _ = _dataflow(name, blocks, labels, True, touch_b)
+    n_asm_vm = _sgpr_hazards(blocks, report)
+    return hazards, {"asm_loads": n_loads, "asm_vmem": n_asm_vm, "block_visits": pa + pb, "blocks": len(blocks), "max_loads_in_flight": fl}
+
+
+_SREG = re.compile(r"\bs(\d+)\b")
+_SRANGE = re.compile(r"\bs\[(\d+):(\d+)\]")
+
+
+def sgprs(operands: str) -> frozenset:
+    out = set(int(m.group(1)) for m in _SREG.finditer(operands))
+    for m in _SRANGE.finditer(operands):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return frozenset(out)
+
+
+def _sgpr_hazards(blocks, report) -> int:
+    """(C) gfx9 "manually inserted wait states": a VALU instruction that writes an SGPR (v_readfirstlane / v_readlane, a compare
+    or carry-out into an SGPR pair) must be followed by 5 wait states before a VMEM instruction reads that SGPR. The compiler's
+    hazard recognizer inserts them for its own instructions — it cannot see the operands of an INLINE-ASM memory instruction.
+    This is what made the first RDX_CHECK_BOUNDS build fault: `v_readfirstlane_b32 s14, v0` directly in front of
+    the asm `global_load_dwordx4 ..., s[14:15]` — the load took its base from a register pair not yet written.
+    Straight-line scan (a label or a branch ends the window: both cost the wait states many times over)."""
+    n_asm_vm = 0
+    for blk in blocks:
+        for i, ins in enumerate(blk):
+            if not (ins.asm and ins.vm):
+                continue
+            n_asm_vm += 1
+            ops = ins.text.split(None, 1)[1].split(";")[0] if " " in ins.text or "\t" in ins.text else ""
+            need = sgprs(ops)
+            if not need:
+                continue
+            waits, j = 0, i - 1
+            while j >= 0 and waits < 5:
+                prev = blk[j]
+                if prev.op == "s_nop":
+                    try:
+                        waits += int(prev.text.split()[1], 0) + 1
+                    except (IndexError, ValueError):
+                        waits += 1
+                    j -= 1
+                    continue
+                if prev.op.startswith("v_"):
+                    pops = prev.text.split(None, 1)[1].split(";")[0] if len(prev.text.split(None, 1)) > 1 else ""
+                    first = pops.split(",")[0]
+                    wr = sgprs(first) if not _V1.search(first) and not _VR.search(first) else frozenset()
+                    if wr & need:
+                        report(f"asm VMEM reads s{sorted(wr & need)} {waits} wait state(s) after a VALU wrote it (5 required)", prev, _Fake(ins))
+                waits += 1
+                j -= 1
+    return n_asm_vm
+
+
+class _Fake:
+    """adapter so that report() can print an (instruction, instruction) pair that is not a (toucher, load) pair"""
+
+    def __init__(self, ins):
+        self.line, self.text, self.dst = ins.line, ins.text, frozenset()
+
+
+def check_listing(text: str, only: str = "k_scan"):
+    """every function whose symbol contains `only` -> {symbol: (hazards, stats)}"""
+    out = {}
+    for name, lines in split_functions(text).items():
+        if only in name:
+            out[name] = check_function(name, lines)
+    return out
+
+
+def main(argv):
+    rc = 0
+    for path in argv:
+        res = check_listing(open(path).read())
+        bad = {k: v for k, v in res.items() if v[0]}
+        print(f"{path}: {len(res)} k_scan kernels, {sum(v[1]['asm_loads'] for v in res.values())} asm loads, "
+              f"{sum(v[1]['block_visits'] for v in res.values())} block visits, {len(bad)} kernels with hazards")
+        for k, (hz, st) in bad.items():
+            rc = 1
+            print(f"  {k}: {len(hz)} hazard(s) {st}")
+            for h in hz[:12]:
+                print(f"    [{h['kind']}] line {h['line']}: {h['text']}\n      <-> line {h['load_line']}: {h['load_text']} (registers {h['regs']})")
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
