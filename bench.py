@@ -576,6 +576,7 @@ def main():
             "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4),"exact_fallback_queries": stats["exact_queries"],
                            "emitted_per_query": round(stats["emitted"] / max(1, B), 1),
                            "rescored_per_query": round(stats["rescored"] / max(1, B), 2), "sample_rows": stats["sample_rows"],
+                           "tau_rank": int(stats["tau_rank"]), "retried_queries": stats["retried_queries"],
                            "xcd_finish_spread_ms": round(stats["xcd_finish_spread_ms"], 4),
                            "xcd_share_min_max": [round(stats["xcd_share_min"], 3), round(stats["xcd_share_max"], 3)],
                            "ms": {n_: round(stats[n_], 4) for n_ in ("ms_normalize", "ms_scan_sample", "ms_tau", "ms_scan_main",

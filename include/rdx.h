@@ -110,6 +110,9 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * "fuse_epilogue" 0/1 (default 1): B > 128 main scan variant whose per-tile emit check rides inside the
  * first k-step of the next tile instead of interrupting the MFMA stream (speed only: +1 % at B = 1024; used when the
  * number of 64-element k-steps per row is even, the stand-alone check otherwise and with 0);
+ * "spec_tau" 0/1 (default 1): the scan threshold is taken from a rank below k of the sampled scores — an estimate of the corpus'
+ * k-th score instead of a proven lower bound — and verified per query afterwards (c_k - 2E >= threshold); a query that fails
+ * takes the fallback passes with the proven threshold (speed only: 2-6x fewer candidates; never results);
  * "retry" 0/1 (default 1): queries whose candidate
  * segments overflow get a second MFMA pass as a small batch (denser threshold sample) before the exact full scan. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);
@@ -201,7 +204,7 @@ typedef struct rdx_search_stats {
     int64_t retried_queries;  /* queries whose candidate segments overflowed and that got a second MFMA pass */
     float xcd_finish_spread_ms; /* main scan: last XCD's finish minus first XCD's finish (0 when not measured) */
     float xcd_share_min, xcd_share_max; /* smallest / largest XCD share of the tiles (1.0 = an eighth) used by that scan */
-    float reserved0;
+    float tau_rank;           /* rank of the sampled score the scan threshold was taken from: k = provable, < k = speculative (verified per query) */
 } rdx_search_stats;
 int rdx_search_last_stats(rdx_index* h, rdx_search_stats* out);
 

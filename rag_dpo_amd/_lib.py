@@ -38,7 +38,7 @@ class SearchStats(ctypes.Structure):
         ("scan_main_launch_rows", ctypes.c_int64), ("scan_main_launch_queries", ctypes.c_int64),
         ("retried_queries", ctypes.c_int64),
         ("xcd_finish_spread_ms", ctypes.c_float), ("xcd_share_min", ctypes.c_float), ("xcd_share_max", ctypes.c_float),
-        ("reserved0", ctypes.c_float),
+        ("tau_rank", ctypes.c_float),
     ]
 
     def as_dict(self):

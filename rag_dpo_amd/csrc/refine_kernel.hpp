@@ -16,7 +16,7 @@ struct RefineCounters {   // one per index, zeroed before every search
     int n_exact;          // queries handed to the exact full scan
     int bad;              // set by K1 when a query embedding holds NaN/Inf
     int oob;              // RDX_CHECK_BOUNDS builds: the scan computed a corpus address outside the scan copy
-    int pad0;
+    int spec_fail;        // queries whose speculative threshold could not be verified (k_refine; they take the fallback passes)
     // option profile = 3 (kernels stamp their own times, no HIP events on the stream): when the first block of the exact path's
     // scoring kernel started (kept as max(~clock): zero = unset) and when the last block of its select kernel ended (100 MHz ticks)
     unsigned long long t_first_inv, t_last;
@@ -28,7 +28,7 @@ struct Mailbox {
     unsigned long long seq;            // written last, system-scope release: search number `seq` is complete
     unsigned long long emitted, rescored;
     int n_exact, bad;
-    int oob, pad0;
+    int oob, spec_fail;
     unsigned long long t_first, t_last;   // profile = 3, exact path (see RefineCounters)
     unsigned long long wg_times[1024]; // [grid][2] start/end stamps of the main scan's workgroups (XCD balancing)
 };
@@ -66,6 +66,8 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
         mb->n_exact = ctr->n_exact;
         mb->bad = ctr->bad;
         mb->oob = ctr->oob;
+        mb->spec_fail = ctr->spec_fail;
+        ctr->spec_fail = 0;
         mb->t_first = ~ctr->t_first_inv;
         mb->t_last = ctr->t_last;
         ctr->t_first_inv = 0;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand,
                                                 int64_t row_base, const int64_t* __restrict__ row_map,
                                                 float* __restrict__ out_score, int64_t* __restrict__ out_row,
                                                 int32_t* __restrict__ out_count, int32_t* __restrict__ exact_list,
-                                                RefineCounters* __restrict__ ctr) {
+                                                RefineCounters* __restrict__ ctr, const float* __restrict__ tau, float inv_scale2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2* list = reinterpret_cast<uint2*>(smem);                        // [REFINE_LIST]
     __shared__ __attribute__((aligned(16))) uint32_t hist[HIST_WORDS];
@@ -154,6 +156,20 @@ __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand,
     int64_t n_gt;
     const uint32_t kth = block_kth_largest([&](int64_t i) { return f2key(__uint_as_float(list[i].x)); }, m, kk, hist, bc, &n_gt);
     const float t2 = key2f(kth) - two_e;
+    // Verification of the scan's threshold T (score units). The hits are exactly the allowed rows with coarse >= T. The k best of
+    // them have exact >= c_k - E, so the exact k-th best of the corpus is >= c_k - E and every true top-k row has coarse >=
+    // c_k - 2E: all of those were emitted iff c_k - 2E >= T (and k hits exist at all). A threshold taken from k sampled rows
+    // (k_tau with rank k) passes by construction; a SPECULATIVE one (rank < k: an estimate of where the corpus' k-th score
+    // lies) passes unless the estimate was too high — then the query goes to the fallback passes, which use
+    // the provable threshold. T = -inf (fewer than k sets sampled): every allowed row was emitted, nothing to verify.
+    const float tq = tau[q] * inv_scale2;
+    if (tq > -INFINITY && ((int64_t)m < (int64_t)k || t2 < tq)) {
+        if (threadIdx.x == 0) {
+            atomicAdd(&ctr->spec_fail, 1);
+            exact_list[atomicAdd(&ctr->n_exact, 1)] = q;
+        }
+        return;
+    }
     if (threadIdx.x == 0) n_p = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {

@@ -700,6 +700,8 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
 // K3a. tau[q] = (k-th largest of the query's set maxima) - 2E, in accumulator units; -inf if fewer than k
 // non-empty sets exist (then every allowed row is emitted). One block per query (padding queries: +inf).
 // Only the first n_sets_used sets (streams that scanned at least one tile) are looked at.
+// k = rank taken: the search's k (provable: k distinct sampled rows reach the value, two_e_scaled = 2E) or a smaller rank with
+// two_e_scaled = 0 (speculative threshold, verified by k_refine; rdx_api.hip spec_rank).
 __global__ __launch_bounds__(256) void k_tau(const float* __restrict__ setmax, int n_sets, int n_sets_used, int k,
                                              float two_e_scaled, int nq, float* __restrict__ tau) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[HIST_WORDS];

@@ -51,6 +51,8 @@ def test_random_shapes_match_oracle(oracle):
             opts["retry"] = 0
         if rng.random() < 0.4:
             opts["fuse_epilogue"] = 0   # (default 1)
+        if rng.random() < 0.3:
+            opts["spec_tau"] = 0        # (default 1: speculative threshold, verified per query)
         for name, v in opts.items():
             ix.set_option(name, v)
         es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, k, allow)

@@ -489,6 +489,35 @@ def test_reference_shape_on_the_default_path(eng, oracle, b):
     ix.close()
 
 
+def test_speculative_threshold_is_verified(eng, oracle):
+    """option spec_tau (default on): the scan threshold comes from a rank below k of the sampled scores — an estimate, not a bound —
+    and k_refine verifies it per query. (1) On a random corpus the rank IS below k and the answers are the oracle's. (2) A corpus
+    built to fool the estimate: the only rows near the query all sit in tile 0, which every sample contains — the sample's 7th
+    best is then far above the corpus' k-th best; verification fails, the queries take the fallback passes (proven threshold),
+    the answers are still the oracle's, and the index stops speculating for a while."""
+    n, d, k = 400_000, 128, 10
+    rng = np.random.default_rng(77)
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((70, d)).astype(np.float32)
+    ix = _index(eng, corpus)
+    st = _check(oracle, ix, corpus, q, k, expect_path=0)
+    assert 1 <= st["tau_rank"] < k and st["retried_queries"] == 0 and st["exact_queries"] == 0, st
+    ix.set_option("spec_tau", 0)
+    st0 = _check(oracle, ix, corpus, q, k, expect_path=0)
+    assert st0["tau_rank"] == k and st0["emitted"] > 1.2 * st["emitted"], (st0, st)      # what the speculation saves
+    ix.set_option("spec_tau", 1)
+    ix.close()
+    fool = corpus.copy()
+    for j in range(8):                                     # 8 near-copies of each of the first 3 queries in tile 0, one per wave's 32-row
+        fool[32 * j: 32 * j + 3] = q[:3] + 0.05 * rng.standard_normal((3, d)).astype(np.float32)   # block (8 distinct bootstrap sets); nothing else is close
+    ix = _index(eng, fool)
+    st = _check(oracle, ix, fool, q, k, expect_path=0)
+    assert st["tau_rank"] < k and st["retried_queries"] >= 3, st
+    st = _check(oracle, ix, fool, q, k, expect_path=0)     # backoff: proven thresholds now, nobody retried
+    assert st["tau_rank"] == k and st["retried_queries"] == 0, st
+    ix.close()
+
+
 @pytest.mark.parametrize("k", [256, 300])
 def test_large_k(eng, oracle, k):
     """k = 256 is the largest the MFMA path serves, k = 300 goes through the exact full scan."""
