@@ -113,6 +113,10 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * "spec_tau" 0/1 (default 1): the scan threshold is taken from a rank below k of the sampled scores — an estimate of the corpus'
  * k-th score instead of a proven lower bound — and verified per query afterwards (c_k - 2E >= threshold); a query that fails
  * takes the fallback passes with the proven threshold (speed only: 2-6x fewer candidates; never results);
+ * "split_boot" 0/1 (default 1): searches of <= 64 queries whose threshold sample is small take it with the split-K bootstrap
+ * kernel (one 32-row block per workgroup, the k-steps dealt to its waves) instead of whole tiles on a few CUs;
+ * "fuse_finish" 0/1 (default 1): the end-of-search work (counters and small results to pinned host memory) runs in the last
+ * block of the search's last kernel instead of a launch of its own (both: speed only);
  * "retry" 0/1 (default 1): queries whose candidate
  * segments overflow get a second MFMA pass as a small batch (denser threshold sample) before the exact full scan. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);

@@ -387,11 +387,11 @@ __device__ unsigned long long g_select_stamps[16];
 #else
 #define RDX_STAMP(i) do { } while (0)
 #endif
-__global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__ scores, int64_t rows,
-                                                       const int32_t* __restrict__ q_list, int k, int64_t row_base,
-                                                       const int64_t* __restrict__ row_map,
-                                                       float* __restrict__ out_score, int64_t* __restrict__ out_row,
-                                                       int32_t* __restrict__ out_count, unsigned long long* __restrict__ t_last) {
+__device__ __forceinline__ void select_dense_query(const float* __restrict__ scores, int64_t rows,
+                                                   const int32_t* __restrict__ q_list, int k, int64_t row_base,
+                                                   const int64_t* __restrict__ row_map,
+                                                   float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                                   int32_t* __restrict__ out_count, unsigned long long* __restrict__ t_last) {
     __shared__ __attribute__((aligned(16))) uint32_t hist[HIST_WORDS];
     __shared__ uint32_t bc[4];
     __shared__ float s_s[SELECT_MAX_K];

@@ -134,6 +134,8 @@ struct rdx_index {
 
     // options
     int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 1, force_bn = 0;
+    int split_boot = 1;      // option: k_boot (K loop split over the waves) for the threshold bootstrap of small launches
+    int fuse_finish = 1;     // option: the end-of-search work runs in the last block of the search's last kernel (0: its own launch k_finish)
     int spec_tau = 1;        // option: speculative scan threshold (rank < k of the sample, verified by k_refine)
     int spec_backoff = 0;    // searches left during which the provable threshold is used (set when a speculation failed)
     double xw[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // relative speed of the XCDs as the last main scans showed it (sum 8)
@@ -364,6 +366,8 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "sib_sync") h->sib_sync = value != 0;
     else if (n == "retry") h->retry = value != 0;
     else if (n == "fuse_epilogue") h->fuse_epilogue = value != 0;
+    else if (n == "fuse_finish") h->fuse_finish = value != 0;
+    else if (n == "split_boot") h->split_boot = value != 0;
     else if (n == "spec_tau") {
         h->spec_tau = value != 0;
         h->spec_backoff = 0;
@@ -700,7 +704,8 @@ static const int K_FAST_MAX = 256;   // larger k goes through the exact full sca
 
 // exact full scan for the queries listed in d_list[0..n_list)
 static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, const uint32_t* d_allow, float* d_score,
-                     int64_t* d_row, int32_t* d_count, hipStream_t st, bool stamps = false) {
+                     int64_t* d_row, int32_t* d_count, hipStream_t st, bool stamps = false, const FinishArgs* fin = nullptr) {
+    const FinishArgs no_fin = {};   // (ctr == NULL: the launch does not end a search)
     // profile = 3: the scoring kernel's first block and the select kernel's last block leave their times in the counter block
     unsigned long long* t_first = stamps ? reinterpret_cast<unsigned long long*>(h->ctr.as<char>() + offsetof(RefineCounters, t_first_inv)) : nullptr;
     unsigned long long* t_last = stamps ? reinterpret_cast<unsigned long long*>(h->ctr.as<char>() + offsetof(RefineCounters, t_last)) : nullptr;
@@ -725,7 +730,7 @@ static int run_exact(rdx_index* h, const int32_t* d_list, int n_list, int k, con
             HIP_TRY(hipGetLastError());
         }
         hipLaunchKernelGGL(k_select_dense, dim3(nq), dim3(1024), 0, st, h->dense.as<float>(), h->rows, d_list + j0, k, h->row_base,
-                           h->row_map, d_score, d_row, d_count, t_last);
+                           h->row_map, d_score, d_row, d_count, t_last, (fin && j0 + QX >= n_list) ? *fin : no_fin);
         HIP_TRY(hipGetLastError());
     }
     return RDX_OK;
@@ -850,6 +855,34 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
     int64_t sample_rows = 0;
     int grid = 0, G = 0, nqt = 0;
     bool balance = false;
+    // K6 (end of search): results of small host calls -> pinned staging, counters (+ workgroup stamps) -> mailbox, counter block
+    // re-zeroed, sequence number published. Runs in the last block of the search's last kernel (option fuse_finish, default) or
+    // as its own launch behind it.
+    const size_t b_s = (size_t)nq * k * 4, b_r = (size_t)nq * k * 8, b_c = (size_t)nq * 4;
+    const bool ride = ho && b_s + b_r + b_c <= PIN_MAX;
+    if (ride) RDX_TRY(ensure_pin_out(h, b_s + b_r + b_c));
+    auto finish_args = [&](bool stamps) {
+        FinishArgs f = {};
+        f.ctr = h->ctr.as<RefineCounters>();
+        f.mb = h->mbox_dev;
+        f.seq = seq;
+        f.wgt = stamps ? h->wgt.as<unsigned long long>() : nullptr;
+        f.n_wgt = stamps ? 2 * grid : 0;
+        f.s0 = reinterpret_cast<const uint32_t*>(d_row);
+        f.d0 = reinterpret_cast<uint32_t*>(h->pin_out_dev);
+        f.w0 = (int64_t)(ride ? b_r / 4 : 0);
+        f.s1 = reinterpret_cast<const uint32_t*>(d_score);
+        f.d1 = reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r);
+        f.w1 = (int64_t)(ride ? b_s / 4 : 0);
+        f.s2 = reinterpret_cast<const uint32_t*>(d_count);
+        f.d2 = reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r + b_s);
+        f.w2 = (int64_t)(ride ? b_c / 4 : 0);
+        f.out_flags = depth == 0 ? d_flags : nullptr;
+        f.may_redo = (!exact_only && depth == 0) ? 1 : 0;
+        return f;
+    };
+    const FinishArgs no_fin = {};
+    FinishArgs fin_later = {};   // fuse_finish = 0: what the stand-alone k_finish gets
     if (exact_only) {
         for (int i = 2; i <= 3; ++i) mark(i);   // events 3..4 bracket the dominant kernels of this path too (K5a + K5b)
         if ((size_t)nq_pad * 4 > h->iota.bytes) {   // identity query list, uploaded once (grow-only), not per search
@@ -860,7 +893,9 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
             HIP_TRY(hipMemcpyAsync(h->iota.p, io.data(), cnt * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
-        RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st, prof_stamps));
+        fin_later = finish_args(false);
+        RDX_TRY(run_exact(h, h->iota.as<int32_t>(), (int)nq, k, d_allow, d_score, d_row, d_count, st, prof_stamps,
+                          h->fuse_finish ? &fin_later : nullptr));
         for (int i = 4; i <= 5; ++i) mark(i);
     } else {
         // queries per workgroup: 64 (tile resident in LDS), 128, 256. 257..384 queries run as three 128-query tiles rather than
@@ -897,7 +932,20 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
             }
         }
         sample_rows = n_sched * 256;
-        const int n_sets_used = (int)std::min<int64_t>(n_streams, n_sched) * SETS_PER_STREAM;
+        int n_sets_used = (int)std::min<int64_t>(n_streams, n_sched) * SETS_PER_STREAM;
+        // Small launches (<= 64 queries and a sample of at most four 32-row blocks per CU): the split-K bootstrap k_boot — one
+        // 32-row block per workgroup, the k-steps dealt to the waves — instead of a few whole tiles of 16 dependent k-steps on
+        // a few CUs (scan_kernel.hpp K2b). Whole rounds of the CUs when more than one.
+        const int64_t n_blocks32 = (h->rows + 31) / 32;
+        int64_t boot_units = std::min<int64_t>(n_blocks32, n_sched * 8);
+        if (boot_units > h->n_cu) boot_units = boot_units / h->n_cu * h->n_cu;
+        const bool use_boot = h->split_boot && bn == BOOT_BN && nqt == 1 && boot_units <= 4 * (int64_t)h->n_cu;
+        int boot_sets = 0;
+        if (use_boot) {
+            sample_rows = boot_units * 32;
+            boot_sets = (int)boot_units * 4;
+            n_sets_used = boot_sets;
+        }
         // slots per (query, stream) segment: 8x the expected hits, power of two, [32, 4096]
         const double exp_hits = (1.5 * k * (double)h->rows / (double)std::max<int64_t>(sample_rows, 1) + k) / n_streams;
         // (slots cost address space, not bandwidth: only occupied slots are ever touched)
@@ -910,7 +958,7 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         RDX_TRY(h->tau.ensure((size_t)nq_pad * 4));
         RDX_TRY(h->cntw.ensure((size_t)nq_pad * n_streams * 4));
         RDX_TRY(h->cand.ensure((size_t)nq_pad * n_streams * capw * 8));
-        RDX_TRY(h->setmax.ensure((size_t)nq_pad * n_sets * 4));
+        RDX_TRY(h->setmax.ensure((size_t)nq_pad * std::max(n_sets, boot_sets) * 4));
 
         ScanParams p = {};
         p.shadow = h->shadow;
@@ -936,8 +984,23 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         p.sib = (nqt > 1 && nqt <= 16 && h->ksteps >= 4 && h->sib_sync) ? reinterpret_cast<uint32_t*>(h->ctr.as<char>() + SIB_OFF) : nullptr;
         if (p.sib) HIP_TRY(hipMemsetAsync(h->ctr.as<char>() + SIB_OFF, 0, SIB_BYTES, st));   // sibling progress bytes (option sib_sync only)
 
-        p.tile_stride = div;
-        RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn, res, p, grid, st));
+        if (use_boot) {
+            BootParams bp = {};
+            bp.shadow = h->shadow;
+            bp.qshadow = h->qshadow.as<_Float16>();
+            bp.ksteps = h->ksteps;
+            bp.rows = h->rows;
+            bp.n_blocks32 = n_blocks32;
+            bp.units = (int)boot_units;
+            bp.allow = d_allow;
+            bp.setmax = h->setmax.as<float>();
+            bp.n_sets = boot_sets;
+            hipLaunchKernelGGL(k_boot, dim3((unsigned)boot_units), dim3(512), 0, st, bp);
+            HIP_TRY(hipGetLastError());
+        } else {
+            p.tile_stride = div;
+            RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn, res, p, grid, st));
+        }
         mark(2);
         // Speculative threshold. The provable threshold is the k-th largest sampled score: k/S of the sample's
         // quantile scale where the corpus' k-th score sits at k/N — with a 1.6 % sample and k = 10 that is 60x the hits one
@@ -961,8 +1024,12 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         }
         if (depth == 0 && h->spec_backoff > 0) --h->spec_backoff;
         acc_stats->tau_rank = (float)k_sel;
-        hipLaunchKernelGGL(k_tau, dim3(nq_pad), dim3(256), 0, st, h->setmax.as<float>(), n_sets, n_sets_used, k_sel,
-                           k_sel == k ? h->two_e() * std::ldexp(1.0f, 2 * h->scale_log2) : 0.0f, (int)nq, h->tau.as<float>());
+        // proven threshold: 2E below the k-th sampled score — plus, when the sample was summed in another order than the main scan
+        // sums (k_boot), twice the fp32 accumulation bound, so that the verification (c_k - 2E >= T, with c_k from the main
+        // scan's sums) cannot fail on a rounding difference between the two orders
+        const float slack = h->two_e() + (use_boot ? 2.0f * (float)h->dim_pad * 1.1920929e-7f : 0.0f);
+        hipLaunchKernelGGL(k_tau, dim3(nq_pad), dim3(256), 0, st, h->setmax.as<float>(), use_boot ? boot_sets : n_sets, n_sets_used, k_sel,
+                           k_sel == k ? slack * std::ldexp(1.0f, 2 * h->scale_log2) : 0.0f, (int)nq, h->tau.as<float>());
         HIP_TRY(hipGetLastError());
         mark(3);
         p.tile_stride = 1;
@@ -1003,33 +1070,27 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
             while (list_cap < (uint32_t)REFINE_LIST && list_cap < 16.0 * exp_hits * n_streams) list_cap *= 2;
             list_cap = std::min<uint32_t>(list_cap, REFINE_LIST);
             const size_t lds = (size_t)list_cap * 8;
+            fin_later = finish_args((balance || prof_stamps) && grid <= 512);
             RDX_TRY(ensure_dynamic_lds(h, (const void*)k_refine, lds));
             hipLaunchKernelGGL(k_refine, dim3((int)nq), dim3(1024), lds, st, h->cand.as<uint2>(), h->cntw.as<uint32_t>(), n_streams, capw,
                                list_cap, k, h->two_e(), h->qhat.as<float>(), h->mv(), h->dim, h->row_base, h->row_map, d_score, d_row, d_count,
-                               h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>(), h->tau.as<float>(), p.inv_scale2);
+                               h->exact_list.as<int32_t>(), h->ctr.as<RefineCounters>(), h->tau.as<float>(), p.inv_scale2,
+                               h->fuse_finish ? fin_later : no_fin);
             HIP_TRY(hipGetLastError());
         }
         mark(5);
     }
-    // K6: results of small host calls -> pinned staging, counters (+ workgroup stamps) -> mailbox, counter block re-zeroed
-    const size_t b_s = (size_t)nq * k * 4, b_r = (size_t)nq * k * 8, b_c = (size_t)nq * 4;
-    const bool ride = ho && b_s + b_r + b_c <= PIN_MAX;
-    if (ride) RDX_TRY(ensure_pin_out(h, b_s + b_r + b_c));
-    if (ho && !ride) {
+    if (!h->fuse_finish) {
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, st, fin_later);
+        HIP_TRY(hipGetLastError());
+    }
+    if (ho && !ride) {   // large host results: plain copies behind the last kernel (complete_chunk synchronises the stream for them)
         if (k > 0) {
             HIP_TRY(hipMemcpyAsync(ho->score, d_score, b_s, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(ho->row, d_row, b_r, hipMemcpyDeviceToHost, st));
         }
         HIP_TRY(hipMemcpyAsync(ho->count, d_count, b_c, hipMemcpyDeviceToHost, st));
     }
-    const bool stamps = (balance || (prof_stamps && !exact_only)) && grid <= 512;
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, st, h->ctr.as<RefineCounters>(), h->mbox_dev, seq,
-                       stamps ? h->wgt.as<unsigned long long>() : (const unsigned long long*)nullptr, stamps ? 2 * grid : 0,
-                       reinterpret_cast<const uint32_t*>(d_row), reinterpret_cast<uint32_t*>(h->pin_out_dev), (int64_t)(ride ? b_r / 4 : 0),
-                       reinterpret_cast<const uint32_t*>(d_score), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r), (int64_t)(ride ? b_s / 4 : 0),
-                       reinterpret_cast<const uint32_t*>(d_count), reinterpret_cast<uint32_t*>(h->pin_out_dev + b_r + b_s), (int64_t)(ride ? b_c / 4 : 0),
-                       depth == 0 ? d_flags : (int32_t*)nullptr, (!exact_only && depth == 0) ? 1 : 0);
-    HIP_TRY(hipGetLastError());
     PendingSearch ps;
     ps.active = true;
     ps.d_queries = d_queries;
@@ -1207,7 +1268,10 @@ static int complete_chunk_impl(rdx_index* h, const PendingSearch& ps, rdx_search
         acc_stats->ms_total += tot;
     } else if (prof_main) {
         float ms = 0;
-        (void)hipEventElapsedTime(&ms, h->ev[3], h->ev[4]);   // both completed: the mailbox came after them in the stream
+        // non-exact path: both completed (the mailbox came after them in the stream). Exact path: ev[4] sits right behind the
+        // kernel whose last block published the mailbox: wait for it (microseconds)
+        if (exact_only) (void)hipEventSynchronize(h->ev[4]);
+        (void)hipEventElapsedTime(&ms, h->ev[3], h->ev[4]);
         acc_stats->profiled = 2;
         if (exact_only) acc_stats->ms_exact += ms;   // exact path: K5a + K5b
         else acc_stats->ms_scan_main += ms;

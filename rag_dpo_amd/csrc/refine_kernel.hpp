@@ -20,6 +20,8 @@ struct RefineCounters {   // one per index, zeroed before every search
     // option profile = 3 (kernels stamp their own times, no HIP events on the stream): when the first block of the exact path's
     // scoring kernel started (kept as max(~clock): zero = unset) and when the last block of its select kernel ended (100 MHz ticks)
     unsigned long long t_first_inv, t_last;
+    int done;             // blocks of the search's last kernel that have finished (the last one runs the end-of-search work)
+    int pad1;
 };
 
 // What the LAST kernel of a search leaves in pinned host memory (written straight over PCIe, no memcpy, no interrupt):
@@ -36,17 +38,29 @@ struct Mailbox {
 // K6. End of every search: (1) small results of HOST callers go from the device result buffers to pinned host staging,
 // (2) the counters (and the workgroup stamps) go to the mailbox, (3) the counter block is zeroed for the next search
 // (searches on one index are serialised by its mutex and each one has completed before the next is enqueued),
-// (4) the sequence number is published. One block: the volumes are KBs.
-__global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ctr, Mailbox* __restrict__ mb, unsigned long long seq,
-                                                const unsigned long long* __restrict__ wgt, int n_wgt,
-                                                const uint32_t* __restrict__ s0, uint32_t* __restrict__ d0, int64_t w0,
-                                                const uint32_t* __restrict__ s1, uint32_t* __restrict__ d1, int64_t w1,
-                                                const uint32_t* __restrict__ s2, uint32_t* __restrict__ d2, int64_t w2,
-                                                int32_t* __restrict__ out_flags, int may_redo) {
-    for (int64_t i = threadIdx.x; i < w0; i += blockDim.x) d0[i] = s0[i];
-    for (int64_t i = threadIdx.x; i < w1; i += blockDim.x) d1[i] = s1[i];
-    for (int64_t i = threadIdx.x; i < w2; i += blockDim.x) d2[i] = s2[i];
-    for (int i = threadIdx.x; i < n_wgt; i += blockDim.x) mb->wg_times[i] = wgt[i];
+// (4) the sequence number is published. The volumes are KBs: ONE block does it — since round 3 the last block to finish of the
+// search's last kernel (k_refine / k_select_dense: finish_if_last below), which saves a launch and a gap on every search; the
+// stand-alone kernel k_finish remains for option "fuse_finish" = 0.
+struct FinishArgs {
+    RefineCounters* ctr;     // NULL: this launch does not end a search
+    Mailbox* mb;
+    unsigned long long seq;
+    const unsigned long long* wgt;
+    int n_wgt;
+    const uint32_t* s0; uint32_t* d0; int64_t w0;
+    const uint32_t* s1; uint32_t* d1; int64_t w1;
+    const uint32_t* s2; uint32_t* d2; int64_t w2;
+    int32_t* out_flags;
+    int may_redo;
+};
+
+__device__ __forceinline__ void finish_body(const FinishArgs& f) {   // all threads of ONE block
+    RefineCounters* ctr = f.ctr;
+    Mailbox* mb = f.mb;
+    for (int64_t i = threadIdx.x; i < f.w0; i += blockDim.x) f.d0[i] = f.s0[i];
+    for (int64_t i = threadIdx.x; i < f.w1; i += blockDim.x) f.d1[i] = f.s1[i];
+    for (int64_t i = threadIdx.x; i < f.w2; i += blockDim.x) f.d2[i] = f.s2[i];
+    for (int i = threadIdx.x; i < f.n_wgt; i += blockDim.x) mb->wg_times[i] = f.wgt[i];
     // every storing wave waits for its own stores, the barrier collects the waves, and ONE lane makes the block's stores visible to
     // the host (system-scope release) before it publishes the sequence number — not a system-scope fence in all 1024 threads
     // (MI355X_MICROARCH.md, inter-workgroup visibility: "every storing wave's s_waitcnt vmcnt(0) -> __syncthreads() -> lane-0 fence")
@@ -55,11 +69,11 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
     if (threadIdx.x == 0) {
         // rdx_search_async(out_flags): "this partial is incomplete, the host half will redo some queries" — the word travels with
         // the packed partial through the all-gather (include/rdx.h); the same condition complete_chunk reports as *redone
-        if (out_flags) {
-            out_flags[0] = (may_redo && ctr->n_exact > 0 && !ctr->bad) ? 1 : 0;
-            out_flags[1] = 0;
-            out_flags[2] = 0;
-            out_flags[3] = 0;
+        if (f.out_flags) {
+            f.out_flags[0] = (f.may_redo && ctr->n_exact > 0 && !ctr->bad) ? 1 : 0;
+            f.out_flags[1] = 0;
+            f.out_flags[2] = 0;
+            f.out_flags[3] = 0;
         }
         mb->emitted = ctr->emitted;
         mb->rescored = ctr->rescored;
@@ -77,10 +91,34 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
         ctr->rescored = 0;
         ctr->n_exact = 0;
         ctr->bad = 0;
+        ctr->done = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the block's stores (L2 written back) before the flag
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (always, behind a release fence: the compiler may drop its own wait)
-        __hip_atomic_store(&mb->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mb->seq, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__global__ __launch_bounds__(1024) void k_finish(const FinishArgs f) { finish_body(f); }
+
+// Tail of the search's last kernel (all threads of every block call it, at a point every thread reaches): the block's result
+// stores are drained and released at agent scope by one lane, which takes a ticket; the block holding the last ticket acquires
+// (its CU's L1 may hold stale lines of what the other blocks wrote) and runs the end-of-search work.
+// (MI355X_MICROARCH.md, hand-off forms: storing waves' vmcnt(0) -> barrier -> one lane's release + agent-scope atomic add; the
+//  workgroup whose add came last loads after its acquire and a barrier.)
+__device__ __forceinline__ void finish_if_last(const FinishArgs& f) {
+    if (!f.ctr) return;
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int t = __hip_atomic_fetch_add(&f.ctr->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == (int)gridDim.x - 1;
+        if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_last = last;
+    }
+    __syncthreads();
+    if (s_last) finish_body(f);
 }
 
 // One block per query (256 threads, 1024 when k is large: the exact re-score runs one wave per candidate row).
@@ -90,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_finish(RefineCounters* __restrict__ ct
 //   P = {coarse >= c_k - 2E} contains the exact top-k; P is re-scored exactly from the fp32 master copy (fp64 lane-order
 //   sum, oracle/rdx_oracle.c) and ranked (score desc, row asc).
 //   A segment, list or P overflow cannot be answered here: the query is flagged for the exact full scan.
-__global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
+__device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
                                                 int n_streams, uint32_t capw, uint32_t list_cap, int k, float two_e,
                                                 const float* __restrict__ qhat, MasterView master, int dim,
                                                 int64_t row_base, const int64_t* __restrict__ row_map,
@@ -241,6 +279,30 @@ __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand,
     for (int i = threadIdx.x; i < p; i += blockDim.x) s_r[i] = row_map ? row_map[s_r[i]] : s_r[i] + row_base;
     __syncthreads();
     rank_and_write(s_s, s_r, p, k, o_s, o_r, out_count + q);
+}
+
+__global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
+                                                int n_streams, uint32_t capw, uint32_t list_cap, int k, float two_e,
+                                                const float* __restrict__ qhat, MasterView master, int dim,
+                                                int64_t row_base, const int64_t* __restrict__ row_map,
+                                                float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                                int32_t* __restrict__ out_count, int32_t* __restrict__ exact_list,
+                                                RefineCounters* __restrict__ ctr, const float* __restrict__ tau, float inv_scale2,
+                                                const FinishArgs fin) {
+    refine_query(cand, cntw, n_streams, capw, list_cap, k, two_e, qhat, master, dim, row_base, row_map, out_score, out_row, out_count,
+                 exact_list, ctr, tau, inv_scale2);
+    finish_if_last(fin);
+}
+
+// K5b as a kernel (the per-query work is select_dense_query, k_rows.hpp): the last launch of an exact-path search ends it
+__global__ __launch_bounds__(1024) void k_select_dense(const float* __restrict__ scores, int64_t rows,
+                                                       const int32_t* __restrict__ q_list, int k, int64_t row_base,
+                                                       const int64_t* __restrict__ row_map,
+                                                       float* __restrict__ out_score, int64_t* __restrict__ out_row,
+                                                       int32_t* __restrict__ out_count, unsigned long long* __restrict__ t_last,
+                                                       const FinishArgs fin) {
+    select_dense_query(scores, rows, q_list, k, row_base, row_map, out_score, out_row, out_count, t_last);
+    finish_if_last(fin);
 }
 
 // Second chance for queries whose candidate segments overflowed: their raw vectors are gathered into a small batch

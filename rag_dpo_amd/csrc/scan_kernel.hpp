@@ -697,6 +697,129 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     }
 }
 
+// K2b. Threshold bootstrap for SMALL launches (<= 64 queries, at most a few 32-row blocks per CU): the K loop split over the waves.
+// The scan kernel above samples whole 256-row tiles: a launch that samples 33 tiles (100 k rows, the sample is 8 K rows) keeps
+// 33 of 256 CUs busy with 16 DEPENDENT k-steps each — 19 us of latency for 0.3 us of arithmetic (round 2's c2: the bootstrap
+// was a fifth of the step). Here one workgroup takes ONE 32-row block of the scan copy, wave w takes the k-steps w, w+8, ...
+// of it (all their fragment loads in flight at once: no dependent chain), the eight partial 32 x 64 tiles are summed in LDS
+// (ds_add_f32), and the block's four 8-row sets leave their per-query maxima: 256 workgroups x 32 rows sample the same 8 K
+// rows in one round of two k-steps. The query fragments come straight from the tiled query scan copy into registers (each
+// fragment is used once; no LDS image). The partial sums are added in another order than the main scan adds them: both are
+// within E of the exact score (E bounds fp32 accumulation in ANY order), which is all the threshold's proof uses.
+//   unit u of U -> 32-row block rb = floor(u * n_blocks32 / U); set id = u * 4 + j, j = 8-row group; setmax[query][n_sets]
+struct BootParams {
+    const _Float16* shadow;
+    const _Float16* qshadow;
+    int ksteps;
+    int64_t rows;
+    int64_t n_blocks32;
+    int units;
+    const uint32_t* allow;
+    float* setmax;
+    int n_sets;
+};
+constexpr int BOOT_BN = 64;
+constexpr int BOOT_LD = 32 + 4;   // floats per query in a partial-sum slab [query][row]: a lane's 4 rows are one ds_write_b128, and the 16 lanes of
+                                  // a pass land on 16 distinct bank quads (9 * query mod 16)
+__global__ __launch_bounds__(512) void k_boot(const BootParams p) {
+    // The eight waves' partial tiles meet in LDS WITHOUT atomics: ds_add_f32 measured ~125 cycles per wave-instruction on this chip
+    // (256 of them per workgroup: 20 of the first version's 27 us). Waves 4-7 park their tiles, waves 0-3 add their partner's to
+    // their own and park the sums, and the final pass adds the four slabs.
+    __shared__ __attribute__((aligned(16))) float slab[4][BOOT_BN * BOOT_LD];
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int64_t rb = (int64_t)u * p.n_blocks32 / p.units;
+    const int KS = p.ksteps;
+    constexpr int NB = BOOT_BN / 16;
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* a_base = reinterpret_cast<const char*>(p.shadow) + rb * ((int64_t)KS * 4096) + lane * 16;
+    const char* q_base = reinterpret_cast<const char*>(p.qshadow);   // query block 0 (<= 64 queries): image row r, 16-B chunk c -> slot c ^ ((r >> 1) & 7)
+    // two k-steps per round: 8 corpus + 16 query fragments (96 VGPRs) requested together, then 32 MFMAs
+    for (int ks0 = wave; ks0 < KS; ks0 += 16) {
+        half8 a[2][4], b[2][2][NB];
+        const int ks1 = ks0 + 8 < KS ? ks0 + 8 : ks0;   // (no second step: re-read the first, its products are dropped below)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ks = t ? ks1 : ks0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[t][c] = *reinterpret_cast<const half8*>(a_base + (int64_t)ks * 4096 + c * 1024);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const int r = n * 16 + l15;
+                    b[t][kk][n] = *reinterpret_cast<const half8*>(q_base + ((int64_t)ks * 256 + r) * 128 + (((kk * 4 + lq) ^ ((r >> 1) & 7)) << 4));
+                }
+        }
+        // all 24 requests are out before the first MFMA asks for one (left to itself the scheduler interleaves load, wait, MFMA
+        // with two loads in flight: 24 dependent round trips, the very chain this kernel exists to avoid)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && ks0 + 8 >= KS) break;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][2 * kk], b[t][kk][n], acc[0][n], 0, 0, 0);
+                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][2 * kk + 1], b[t][kk][n], acc[1][n], 0, 0, 0);
+                }
+        }
+    }
+    // acc[m][n] = rows m*16 + lq*4 + 0..3 of query n*16 + l15  ->  slab[query][row]
+    float* mine = slab[wave & 3] + l15 * BOOT_LD + lq * 4;
+    if (wave >= 4) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) *reinterpret_cast<f32x4*>(mine + n * 16 * BOOT_LD + m * 16) = acc[m][n];
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                f32x4* cell = reinterpret_cast<f32x4*>(mine + n * 16 * BOOT_LD + m * 16);
+                const f32x4 o = *cell;
+                *cell = f32x4{acc[m][n][0] + o[0], acc[m][n][1] + o[1], acc[m][n][2] + o[2], acc[m][n][3] + o[3]};
+            }
+    }
+    __syncthreads();
+    // which of the block's 32 rows count (ragged end of the corpus, `where` bitmap: one word per 32-row block)
+    const int64_t row0 = rb * 32;
+    uint32_t ok = 0xffffffffu;
+    const int64_t left = p.rows - row0;
+    if (left < 32) ok = left <= 0 ? 0u : ((1u << left) - 1u);
+    if (p.allow && left > 0) ok &= p.allow[rb];
+    if (threadIdx.x < 4 * BOOT_BN) {
+        const int q = threadIdx.x & (BOOT_BN - 1), j = threadIdx.x / BOOT_BN;   // set j = rows 8j .. 8j+7 of the block
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(slab[w] + q * BOOT_LD + j * 8);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(slab[w] + q * BOOT_LD + j * 8 + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lo[r] += x[r];
+                hi[r] += y[r];
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mx = fmaxf(mx, ((ok >> (j * 8 + r)) & 1u) ? lo[r] : -INFINITY);
+            mx = fmaxf(mx, ((ok >> (j * 8 + 4 + r)) & 1u) ? hi[r] : -INFINITY);
+        }
+        p.setmax[(int64_t)q * p.n_sets + (int64_t)u * 4 + j] = mx;
+    }
+}
+
 // K3a. tau[q] = (k-th largest of the query's set maxima) - 2E, in accumulator units; -inf if fewer than k
 // non-empty sets exist (then every allowed row is emitted). One block per query (padding queries: +inf).
 // Only the first n_sets_used sets (streams that scanned at least one tile) are looked at.

@@ -53,6 +53,10 @@ def test_random_shapes_match_oracle(oracle):
             opts["fuse_epilogue"] = 0   # (default 1)
         if rng.random() < 0.3:
             opts["spec_tau"] = 0        # (default 1: speculative threshold, verified per query)
+        if rng.random() < 0.3:
+            opts["split_boot"] = 0      # (default 1: split-K bootstrap kernel for <= 64 queries)
+        if rng.random() < 0.2:
+            opts["fuse_finish"] = 0     # (default 1: end-of-search work in the last block of the last kernel)
         for name, v in opts.items():
             ix.set_option(name, v)
         es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, k, allow)

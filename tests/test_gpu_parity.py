@@ -489,6 +489,27 @@ def test_reference_shape_on_the_default_path(eng, oracle, b):
     ix.close()
 
 
+@pytest.mark.parametrize("d,n,b,k", [(1024, 100_000, 64, 10), (1024, 70_000, 1, 50), (64, 9000, 40, 10), (200, 30_011, 33, 20),
+                                     (768, 50_000, 64, 100), (2048, 20_000, 7, 10), (128, 257, 3, 5)])
+def test_split_k_bootstrap(eng, oracle, d, n, b, k):
+    """option split_boot (default 1): <= 64 queries with a small threshold sample take it with k_boot — one 32-row block per
+    workgroup, k-steps dealt to the waves, partial sums added in LDS. Ids and score bits are the oracle's with it and without it,
+    with and without a row bitmap (its per-block word, the ragged last block); the sample is the same size or larger."""
+    corpus = synth.make_corpus(n, d)
+    q = synth.make_queries(b, d, corpus)
+    allow = np.random.default_rng(n).random(n) < 0.3
+    seen = {}
+    for sb in (1, 0):
+        ix = _index(eng, corpus, force_fast=1, split_boot=sb)
+        st = _check(oracle, ix, corpus, q, k, expect_path=0)
+        assert st["exact_queries"] == 0 and st["retried_queries"] == 0, (sb, st)
+        _check(oracle, ix, corpus, q, k, allow, expect_path=0)
+        seen[sb] = st
+        ix.close()
+    assert seen[1]["sample_rows"] <= max(4 * 256 * 32, seen[0]["sample_rows"]), seen
+    assert seen[1]["sample_rows"] % 32 == 0 and seen[1]["sample_rows"] >= min(n // 32 * 32, 8192) or n < 8192, seen
+
+
 def test_speculative_threshold_is_verified(eng, oracle):
     """option spec_tau (default on): the scan threshold comes from a rank below k of the sampled scores — an estimate, not a bound —
     and k_refine verifies it per query. (1) On a random corpus the rank IS below k and the answers are the oracle's. (2) A corpus
@@ -674,9 +695,13 @@ def test_clustered_rows_get_a_second_mfma_pass(eng, oracle):
     corpus[a:a + m] = v + sigma * rng.standard_normal((m, dim)).astype(np.float32)
     q = rng.standard_normal((40, dim)).astype(np.float32)
     q[:5] = v + 0.1 * rng.standard_normal((5, dim)).astype(np.float32)
-    ix = _index(eng, corpus, force_fast=1, cand_cap=64)
+    ix = _index(eng, corpus, force_fast=1, cand_cap=64, split_boot=0)     # (whole-tile sample: the stride this corpus is built against)
     st = _check(oracle, ix, corpus, q, k, expect_path=0)
     assert st["retried_queries"] == 5 and st["exact_queries"] == 0, st
+    ix.set_option("split_boot", 1)                 # the split-K bootstrap samples 32-row blocks spread over the corpus: four of them
+    st = _check(oracle, ix, corpus, q, k, expect_path=0)   # fall into the cluster, the threshold sees it, nothing overflows
+    assert st["retried_queries"] == 0 and st["exact_queries"] == 0, st
+    ix.set_option("split_boot", 0)
     ix.set_option("retry", 0)                      # without the second chance the same queries pay the exact scan
     st = _check(oracle, ix, corpus, q, k, expect_path=0)
     assert st["retried_queries"] == 0 and st["exact_queries"] == 5, st
