@@ -527,6 +527,36 @@ class Collection:
                 "included": include,
             }
 
+    def query_device(self, query_embeddings, n_results: int = 10, where=None):
+        """Batch callers that already hold their query embeddings on the GPU (the provider's `embed_device`, reference
+        src/utils/embedding_provider.py:139-145 feeding src/rag/retriever.py:215-220) and want the neighbours there too:
+        `query_embeddings` a [nq][dim] fp32 torch CUDA tensor -> (distances f32[nq, n_results], rows i64[nq, n_results],
+        counts i32[nq]) torch tensors on the collection's (first) device; `ids_of(rows)` maps rows to the Chroma ids. Same
+        filter semantics and the same floats as query() — nothing crosses PCIe but the call itself."""
+        import torch
+        with self._lock:
+            if self._engine is None or self._rows == 0:
+                raise ValueError("query_device: the collection is empty")
+            if not hasattr(self._engine, "search_device"):
+                raise NotImplementedError("this collection's engine has no device-pointer search")
+            q = query_embeddings.contiguous()
+            nq, k = int(q.shape[0]), int(n_results)
+            args = self._search_args(where)
+            if "allow_bits" in args:
+                raise NotImplementedError("query_device needs an engine with resident masks")
+            dev = q.device
+            s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            r = torch.empty((nq, k), dtype=torch.int64, device=dev)
+            c = torch.empty((nq,), dtype=torch.int32, device=dev)
+            self._engine.search_device(q, k, s, r, c, mask=args.get("mask"))
+            return (1.0 - s), r, c            # Chroma cosine distance, fp32 (padding entries: distance +inf, row -1)
+
+    def ids_of(self, rows) -> List[List[str]]:
+        """Chroma ids of row ids as returned by query_device (negative = padding, skipped)"""
+        with self._lock:
+            rr = rows.tolist() if hasattr(rows, "tolist") else rows
+            return [[self._ids[x] for x in row if x >= 0] for row in rr]
+
     def modify(self, name: Optional[str] = None, metadata: Optional[dict] = None):
         with self._lock:
             if name is not None:

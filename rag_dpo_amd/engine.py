@@ -167,8 +167,9 @@ class HipIndex:
         except AttributeError:   # pragma: no cover
             return torch.cuda.current_stream(device).cuda_stream
 
-    def search_device(self, queries, k: int, out_score, out_row, out_count, allow_bits=None):
-        """torch CUDA tensors in/out, enqueued on the current torch stream (no host copies)."""
+    def search_device(self, queries, k: int, out_score, out_row, out_count, allow_bits=None, mask: Optional[ResidentMask] = None):
+        """torch CUDA tensors in/out, enqueued on the current torch stream (no host copies).
+        allow_bits: a device bitmap for this call; mask: a resident one (make_mask) — not both."""
         import torch
         nq = queries.shape[0]
         assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
@@ -176,12 +177,19 @@ class HipIndex:
         assert out_row.shape == (nq, k) and out_row.dtype == torch.int64 and out_row.is_contiguous()
         assert out_count.shape == (nq,) and out_count.dtype == torch.int32
         stream = self._raw_stream(queries.device)
+        if mask is not None:
+            if allow_bits is not None:
+                raise ValueError("pass allow_bits or mask, not both")
+            L.check(self._lib.rdx_search_masked(self._h, ctypes.c_void_p(queries.data_ptr()), nq, int(k), mask._h,
+                                                ctypes.c_void_p(out_score.data_ptr()), ctypes.c_void_p(out_row.data_ptr()),
+                                                ctypes.c_void_p(out_count.data_ptr()), L.RDX_DEVICE, ctypes.c_void_p(stream)))
+            return
         mp = ctypes.c_void_p(allow_bits.data_ptr()) if allow_bits is not None else None
         L.check(self._lib.rdx_search(self._h, ctypes.c_void_p(queries.data_ptr()), nq, int(k), mp,
                                      ctypes.c_void_p(out_score.data_ptr()), ctypes.c_void_p(out_row.data_ptr()),
                                      ctypes.c_void_p(out_count.data_ptr()), L.RDX_DEVICE, ctypes.c_void_p(stream)))
 
-    def search_device_async(self, queries, k: int, out_score, out_row, out_count, out_flags=None):
+    def search_device_async(self, queries, k: int, out_score, out_row, out_count, out_flags=None, mask: Optional[ResidentMask] = None):
         """enqueue the search on the current torch stream and return at once; search_wait() completes it (include/rdx.h).
         `queries` may be reused by stream-ordered work enqueued afterwards; the outputs (and out_flags: int32[4] on the device,
         [0] = 1 while the results are incomplete) must stay valid until search_wait() has returned."""
@@ -193,7 +201,7 @@ class HipIndex:
         assert out_count.shape == (nq,) and out_count.dtype == torch.int32
         assert out_flags is None or (out_flags.numel() >= L.PACKED_FLAGS and out_flags.dtype == torch.int32)
         stream = self._raw_stream(queries.device)
-        L.check(self._lib.rdx_search_async(self._h, ctypes.c_void_p(queries.data_ptr()), nq, int(k), None,
+        L.check(self._lib.rdx_search_async(self._h, ctypes.c_void_p(queries.data_ptr()), nq, int(k), mask._h if mask is not None else None,
                                            ctypes.c_void_p(out_score.data_ptr()), ctypes.c_void_p(out_row.data_ptr()),
                                            ctypes.c_void_p(out_count.data_ptr()),
                                            ctypes.c_void_p(out_flags.data_ptr()) if out_flags is not None else None,
@@ -225,6 +233,19 @@ def l2_normalize(x: np.ndarray, device: int = 0) -> np.ndarray:
     out = np.empty_like(a)
     L.check(lib.rdx_l2_normalize(device, _np_ptr(a), a.shape[0], a.shape[1], _np_ptr(out), L.RDX_HOST, None))
     return out
+
+
+def merge_topk_device(part_score, part_row, part_count, k: int, out_score, out_row, out_count):
+    """rdx_merge_topk on torch CUDA tensors ([P][nq][k], [P][nq][k], [P][nq] on ONE device), enqueued on that device's current
+    torch stream; any P * k (the library folds the parts pairwise beyond what one merge launch ranks)"""
+    lib = L.load(require_gpu=True)
+    P, nq = part_count.shape
+    dev = part_score.device
+    assert part_score.is_contiguous() and part_row.is_contiguous() and part_count.is_contiguous()
+    stream = HipIndex._raw_stream(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    L.check(lib.rdx_merge_topk(dev.index or 0, p(part_score), p(part_row), p(part_count), int(P), int(nq), int(k),
+                               p(out_score), p(out_row), p(out_count), L.RDX_DEVICE, ctypes.c_void_p(stream)))
 
 
 def merge_topk(part_score: np.ndarray, part_row: np.ndarray, part_count: np.ndarray, k: int, device: int = 0):

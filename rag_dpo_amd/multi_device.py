@@ -303,6 +303,82 @@ class MultiDeviceIndex:
         return self._merge(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]), np.stack([p[2] for p in parts]),
                            int(k), self.device)
 
+    def search_device(self, queries, k: int, out_score=None, out_row=None, out_count=None, mask: Optional[MultiMask] = None):
+        """Device in / device out (a batch caller behind `Collection(devices=...)`: nothing crosses PCIe). `queries`: [nq][dim]
+        fp32 torch tensor on the FIRST device, produced on its current stream; the results land on the first device too, enqueued on
+        its current stream: (score f32[nq,k], row i64[nq,k] COLLECTION row ids, count i32[nq]).
+        The batch goes to every other device by a peer copy, every shard's search is ENQUEUED (rdx_search_async: the scans of the D
+        devices run side by side), the host then completes each of them (fallback passes, if any), the partials travel to the
+        first device by peer copies and ONE device merge ranks them. Same arithmetic wherever a row lives: bit-identical to search()."""
+        import torch
+        from .engine import merge_topk_device
+        if k < 1:
+            raise ValueError("search_device needs k >= 1")
+        if mask is not None and mask.rows != self._n:
+            raise ValueError("the mask was made for another state of the rows (a mask does not outlive a write)")
+        dev0 = torch.device("cuda", self.devices[0])
+        if not (queries.is_cuda and queries.device == dev0 and queries.dtype == torch.float32 and queries.dim() == 2
+                and queries.shape[1] == self.dim and queries.is_contiguous()):
+            raise ValueError(f"expected a contiguous [nq][{self.dim}] float32 tensor on {dev0}")
+        nq = int(queries.shape[0])
+        if nq > 4096:
+            raise ValueError("search_device takes at most 4096 queries per call")
+        if out_score is None:
+            out_score = torch.empty((nq, k), dtype=torch.float32, device=dev0)
+            out_row = torch.empty((nq, k), dtype=torch.int64, device=dev0)
+            out_count = torch.empty((nq,), dtype=torch.int32, device=dev0)
+        live = [d for d in range(len(self._shards)) if self._glob[d].n > 0]
+        if not live:
+            out_score.fill_(float("-inf")); out_row.fill_(-1); out_count.zero_()
+            return out_score, out_row, out_count
+        key = (nq, int(k), len(live))
+        bufs = getattr(self, "_dev_bufs", None)
+        if bufs is None or bufs[0] != key:
+            per = {}
+            for d in live:
+                dd = torch.device("cuda", self.devices[d])
+                per[d] = (torch.empty((nq, self.dim), dtype=torch.float32, device=dd) if dd != dev0 else None,
+                          torch.empty((nq, k), dtype=torch.float32, device=dd), torch.empty((nq, k), dtype=torch.int64, device=dd),
+                          torch.empty((nq,), dtype=torch.int32, device=dd))
+            gathered = (torch.empty((len(live), nq, k), dtype=torch.float32, device=dev0),
+                        torch.empty((len(live), nq, k), dtype=torch.int64, device=dev0),
+                        torch.empty((len(live), nq), dtype=torch.int32, device=dev0))
+            bufs = self._dev_bufs = (key, per, gathered)
+        _, per, (g_s, g_r, g_c) = bufs
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev0))            # the batch exists on the first device from here on
+        for d in live:
+            dd = torch.device("cuda", self.devices[d])
+            q_d, s_d, r_d, c_d = per[d]
+            with torch.cuda.device(dd):
+                st = torch.cuda.current_stream(dd)
+                if q_d is not None:
+                    st.wait_event(ready)
+                    q_d.copy_(queries, non_blocking=True)         # peer copy over xGMI, on the receiving device's stream
+                else:
+                    q_d = queries
+                self._shards[d].search_device_async(q_d, k, s_d, r_d, c_d, None, mask.parts[d] if mask is not None else None)
+        for d in live:                                            # host halves: every shard's search complete (results final)
+            self._shards[d].search_wait()
+        if len(live) == 1:
+            _, s_d, r_d, c_d = per[live[0]]
+            out_score.copy_(s_d, non_blocking=True); out_row.copy_(r_d, non_blocking=True); out_count.copy_(c_d, non_blocking=True)
+            return out_score, out_row, out_count
+        s0 = torch.cuda.current_stream(dev0)
+        for i, d in enumerate(live):
+            dd = torch.device("cuda", self.devices[d])
+            _, s_d, r_d, c_d = per[d]
+            with torch.cuda.device(dd):
+                st = torch.cuda.current_stream(dd)
+                g_s[i].copy_(s_d, non_blocking=True); g_r[i].copy_(r_d, non_blocking=True); g_c[i].copy_(c_d, non_blocking=True)
+                if st != s0:
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    s0.wait_event(done)
+        with torch.cuda.device(dev0):
+            merge_topk_device(g_s, g_r, g_c, int(k), out_score, out_row, out_count)
+        return out_score, out_row, out_count
+
     def last_stats(self) -> dict:
         """per-shard stats of the last search, plus the sums of the additive counters"""
         per = [sh.last_stats() for sh in self._shards if hasattr(sh, "last_stats")]

@@ -145,6 +145,21 @@ def test_three_shards_on_one_gpu_equal_one_index(oracle):
         ix.set_option("force_fast", 0); ix.set_option("force_exact", 1)
     same(md.search(q[:5], 300), one.search(q[:5], 300))       # exact path through the id map as well
     same(md.search(q[:5], 2100), one.search(q[:5], 2100))     # 3 x 2100 candidates per query: the library folds the parts pairwise
+    # device in / device out (queries on the first device, peer copies, asynchronous shard searches, ONE device merge)
+    import torch
+    for ix in (one, md):
+        ix.set_option("force_exact", 0); ix.set_option("force_fast", 1)
+    qd = torch.from_numpy(q).cuda()
+    for kk in (10, 300, 2100):                                # 3 x 2100 candidates per query: folded pairwise on the device
+        hs, hr, hc = md.search(q[:9] if kk > 300 else q, kk)
+        ds, dr, dc = md.search_device(qd[:9].contiguous() if kk > 300 else qd, kk)
+        torch.cuda.synchronize()
+        same((ds.cpu().numpy(), dr.cpu().numpy(), dc.cpu().numpy()), (hs, hr, hc))
+    ds, dr, dc = md.search_device(qd, 50, mask=m)
+    torch.cuda.synchronize()
+    same((ds.cpu().numpy(), dr.cpu().numpy(), dc.cpu().numpy()), one.search(q, 50, bits))
+    for ix in (one, md):
+        ix.set_option("force_fast", 0); ix.set_option("force_exact", 1)
     keep = np.flatnonzero(rng.random(n) < 0.5)
     md.compact(keep); one.compact(keep)
     for ix in (one, md):
@@ -159,4 +174,11 @@ def test_three_shards_on_one_gpu_equal_one_index(oracle):
     ref.add(ids=[f"r{i}" for i in range(2000)], embeddings=corpus[:2000], metadatas=[{"p": i % 3} for i in range(2000)])
     qa = q[:3].tolist()
     assert col.query(query_embeddings=qa, n_results=20, where={"p": 1}) == ref.query(query_embeddings=qa, n_results=20, where={"p": 1})
+    # the same through the device entry of the boundary: distances, rows -> ids
+    for c_ in (col, ref):
+        dist, rows, cnt = c_.query_device(torch.from_numpy(q[:3]).cuda(), n_results=20, where={"p": 1})
+        torch.cuda.synchronize()
+        want = ref.query(query_embeddings=qa, n_results=20, where={"p": 1})
+        assert c_.ids_of(rows.cpu()) == want["ids"] and cnt.tolist() == [20, 20, 20]
+        assert [[float(x) for x in row] for row in dist.cpu().numpy()] == want["distances"]
     md.close(); one.close()
