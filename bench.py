@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--k", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
     ap.add_argument("--no-encode", action="store_true", help="c5: leave the BGE-M3 query encode out of the step")
+    ap.add_argument("--enc-buckets", type=int, default=4, help="c5: most length buckets (forwards) per encoded batch; 1 = one forward padded to the longest text")
     ap.add_argument("--no-overlap", action="store_true", help="c5: encode then search on one stream (no pipelining of batch i+1's encode with batch i's search)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="developer: rdx_index_set_option before the run")
     ap.add_argument("--fp32-master", action="store_true", help="c5: keep the normalised fp32 rows as the exact copy (6 instead of 4 B/element)")
@@ -282,6 +283,7 @@ def main():
         from rag_dpo_amd.embedding_provider import EmbeddingProvider
         provider = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device=str(device), dtype=torch.float16,
                                      batch_size=int(os.environ.get("RDX_ENC_BATCH", "1024"))).load()
+        provider.max_buckets = max(1, args.enc_buckets)
         texts = synth.query_texts(B)
 
     def step():
@@ -430,6 +432,17 @@ def main():
             torch.cuda.synchronize(device)
             merged_ok = bool((wr == mr_).all() and (ws == ms_).all() and (wc == mc_).all())
             whole.index.close()
+    enc_stats = None
+    if encode and rank == 0:
+        # one more encode, outside the timed region, with events around every bucket's forward
+        provider.time_buckets = True
+        provider.embed_device(texts)
+        provider.time_buckets = False
+        es = provider.last_encode_stats
+        enc_stats = {"tokens_real": es["tokens_real"], "tokens_padded": es["tokens_padded"],
+                     "tokens_real_over_padded": es["real_over_padded"],
+                     "tokens_padded_if_one_forward": es["tokens_padded_one_width"], "buckets": es["buckets"],
+                     "rule": "token-count-sorted rows cut into <= %d buckets (multiples of %d rows), each forwarded at its own width" % (provider.max_buckets, provider.bucket_granule)}
     out = None
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -571,7 +584,7 @@ def main():
             "merged_equals_single_index": merged_ok, "rccl": rccl_info, "distributed_check": dist_check, "step_breakdown": step_breakdown,
             "encode": ({"model": "XLM-R-large (BGE-M3 architecture), random-init fp16, hashing tokenizer", "texts_per_step": B,
                         "avg_ms": round(sum(a.elapsed_time(b) for a, b in enc_ev) / max(1, len(enc_ev)), 3),
-                        "pipelined_with_search": bool(serial is not None), "serial_leg": serial,
+                        "pipelined_with_search": bool(serial is not None), "serial_leg": serial, "length_buckets": enc_stats,
                         "note": "encoder value parity unpinned (no BGE-M3 weights offline); PyTorch-ROCm plumbing, not a librdx kernel"} if encode else None),
             "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4),"exact_fallback_queries": stats["exact_queries"],
                            "emitted_per_query": round(stats["emitted"] / max(1, B), 1),

@@ -156,17 +156,88 @@ class EmbeddingProvider:
             if str(self.device).startswith("cuda"):
                 torch.cuda.empty_cache()
 
+    # Length buckets. sentence-transformers (the reference's encoder, src/utils/embedding_provider.py:139-145) sorts a call's texts by
+    # length and pads every batch of `batch_size` to ITS longest text. With the large batches a GPU wants (BASELINE config 5 hands
+    # 1024 query texts to one call) one batch means one width: 8-24-word questions padded to the longest are ~30 % padding
+    # tokens. A batch is therefore cut, after tokenising, into at most `max_buckets` buckets of consecutive (token-count-sorted)
+    # rows, each forwarded at its own width; the cuts (multiples of 64 rows) minimise padded tokens + a per-forward charge.
+    max_buckets = 4
+    bucket_granule = 64
+    bucket_overhead_tokens = 4096      # what one more forward costs, in token-equivalents. Measured on MI355X, XLM-R-large fp16, 1024 questions:
+                                       # ONE forward of 1024 x 28 tokens 23.5 ms; TWO of 512 x 28 + 512 x 20 (14 % fewer tokens) 13.1 + 10.4 = 23.5 ms —
+                                       # the smaller GEMMs and the second pass of ~400 launches eat what the padding saved: ~4 K tokens per forward
+    time_buckets = False               # True: CUDA events around every bucket's forward (last_encode_stats["buckets"][i]["ms"])
+    last_encode_stats: Optional[dict] = None
+
+    def _bucket_cuts(self, lens_desc: np.ndarray) -> List[int]:
+        """row boundaries [0, ..., n] of the buckets for token counts sorted in descending order"""
+        n = int(lens_desc.shape[0])
+        g = max(1, int(self.bucket_granule))
+        cand = list(range(0, n, g)) + [n]
+        m, B = len(cand) - 1, max(1, int(self.max_buckets))
+        if m <= 1 or B == 1:
+            return [0, n]
+        INF = float("inf")
+        cost = [[INF] * (m + 1) for _ in range(B + 1)]    # cost[b][j]: rows [0, cand[j]) in exactly b buckets
+        prev = [[-1] * (m + 1) for _ in range(B + 1)]
+        cost[0][0] = 0.0
+        for b in range(1, B + 1):
+            for j in range(1, m + 1):
+                for i in range(b - 1, j):
+                    if cost[b - 1][i] == INF:
+                        continue
+                    c = cost[b - 1][i] + (cand[j] - cand[i]) * float(lens_desc[cand[i]]) + self.bucket_overhead_tokens
+                    if c < cost[b][j]:
+                        cost[b][j], prev[b][j] = c, i
+        b = min(range(1, B + 1), key=lambda x: cost[x][m])
+        cuts, j = [n], m
+        while b > 0:
+            j = prev[b][j]
+            cuts.append(cand[j])
+            b -= 1
+        return cuts[::-1]
+
     @torch.no_grad()
     def _encode_raw(self, texts: List[str]) -> torch.Tensor:
         """un-normalised CLS embeddings, fp32, on the model's device, in input order"""
         order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))   # length-sorted batches, like sentence-transformers
         out = torch.empty((len(texts), self._dims), dtype=torch.float32, device=self.device)
+        stats = {"texts": len(texts), "tokens_real": 0, "tokens_padded": 0, "tokens_padded_one_width": 0, "buckets": []}
+        events = []
+        on_gpu = str(self.device).startswith("cuda")
         for a in range(0, len(texts), self.batch_size):
             idx = order[a: a + self.batch_size]
             enc = self._tokenizer([texts[i] for i in idx])
-            enc = {k: v.to(self.device) for k, v in enc.items()}
-            hidden = self._model(**enc).last_hidden_state
-            out[torch.tensor(idx, device=self.device)] = hidden[:, 0].to(torch.float32)   # CLS pooling (BGE-M3 dense)
+            ids, att = enc["input_ids"], enc["attention_mask"]
+            lens = att.sum(dim=1)
+            by_len = torch.argsort(lens, descending=True, stable=True)      # characters were a proxy: now by token count
+            ids, att, lens_np = ids[by_len], att[by_len], lens[by_len].numpy()
+            rows = [idx[i] for i in by_len.tolist()]
+            cuts = self._bucket_cuts(lens_np)
+            stats["tokens_real"] += int(lens_np.sum())
+            stats["tokens_padded_one_width"] += int(ids.shape[0] * ids.shape[1])
+            extra = {k: v[by_len] for k, v in enc.items() if k not in ("input_ids", "attention_mask")}
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                w = int(lens_np[lo])                                        # the bucket's longest row (right padding: columns [:w])
+                feed = {"input_ids": ids[lo:hi, :w].to(self.device, non_blocking=True),
+                        "attention_mask": att[lo:hi, :w].to(self.device, non_blocking=True)}
+                feed.update({k: v[lo:hi, :w].to(self.device) for k, v in extra.items()})
+                if self.time_buckets and on_gpu:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                hidden = self._model(**feed).last_hidden_state
+                out[torch.tensor(rows[lo:hi], device=self.device)] = hidden[:, 0].to(torch.float32)   # CLS pooling (BGE-M3 dense)
+                if self.time_buckets and on_gpu:
+                    e1.record()
+                    events.append((len(stats["buckets"]), e0, e1))
+                stats["tokens_padded"] += (hi - lo) * w
+                stats["buckets"].append({"rows": hi - lo, "width": w})
+        if events:
+            torch.cuda.synchronize()
+            for i, e0, e1 in events:
+                stats["buckets"][i]["ms"] = round(e0.elapsed_time(e1), 3)
+        stats["real_over_padded"] = round(stats["tokens_real"] / max(1, stats["tokens_padded"]), 4)
+        self.last_encode_stats = stats
         return out
 
     def embed(self, texts: List[str]) -> List[List[float]]:

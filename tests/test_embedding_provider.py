@@ -151,3 +151,34 @@ def test_local_checkpoint_embed_matches_fp32_reference(tmp_path, oracle):
     p32 = EP.EmbeddingProvider(model_name=ckpt, device="cuda", dtype=torch.float32, batch_size=4)
     out32 = np.asarray(p32.embed(TEXTS), dtype=np.float32)
     assert np.abs(out32 - ref_hat).max() < 2e-5                             # fp32 on the GPU: the same pipeline to fp32 noise
+
+
+def test_length_buckets_change_padding_not_values():
+    """embed_device cuts a batch into token-count buckets (at most max_buckets forwards, each at its own width): fewer padding
+    tokens, the same CLS rows as ONE forward padded to the longest text (attention masks hide the padding either way)."""
+    import torch
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    rng = np.random.default_rng(3)
+    words = [f"w{i}" for i in range(300)]
+    texts = [" ".join(rng.choice(words, size=int(n))) for n in rng.integers(3, 60, size=300)]
+    texts[17] = " ".join(rng.choice(words, size=200))              # one long outlier: the reason one width is wasteful
+    p = EmbeddingProvider(model_name="random-init:tiny", device="cpu", dtype=torch.float32, batch_size=512).load()
+    p.max_buckets, p.bucket_granule, p.bucket_overhead_tokens = 1, 64, 0
+    one = p._encode_raw(texts)
+    s1 = dict(p.last_encode_stats)
+    assert len(s1["buckets"]) == 1 and s1["tokens_padded"] == s1["tokens_padded_one_width"] == 300 * 202
+    p.max_buckets, p.bucket_overhead_tokens = 4, 64
+    four = p._encode_raw(texts)
+    s4 = p.last_encode_stats
+    assert 2 <= len(s4["buckets"]) <= 4 and sum(b["rows"] for b in s4["buckets"]) == 300
+    assert s4["tokens_real"] == s1["tokens_real"] and s4["tokens_padded"] < 0.5 * s1["tokens_padded"]
+    widths = [b["width"] for b in s4["buckets"]]
+    assert widths == sorted(widths, reverse=True) and widths[0] == 202
+    assert torch.allclose(one, four, atol=2e-5, rtol=1e-5)
+    # the cut chooser: optimal on a case small enough to enumerate
+    lens = np.array(sorted(rng.integers(3, 100, size=256).tolist(), reverse=True))
+    p.max_buckets, p.bucket_granule, p.bucket_overhead_tokens = 3, 64, 500
+    cuts = p._bucket_cuts(lens)
+    cost = lambda c: sum((b - a) * lens[a] + 500 for a, b in zip(c[:-1], c[1:]))
+    cands = [[0, 256]] + [[0, i, 256] for i in (64, 128, 192)] + [[0, i, j, 256] for i in (64, 128) for j in (128, 192) if j > i]
+    assert cuts[0] == 0 and cuts[-1] == 256 and cost(cuts) == min(cost(c) for c in cands)
