@@ -121,6 +121,13 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * segments overflow get a second MFMA pass as a small batch (denser threshold sample) before the exact full scan. */
 int rdx_index_set_option(rdx_index* h, const char* name, int64_t value);
 
+/* The main scan's tile shares of the 8 XCDs (1.0 = an eighth; option "xcd_balance"): learned from the workgroups' own time stamps
+ * over the first searches of a process — the first launches of a cold index run with even shares, ~15 % slower on a 10 M-row
+ * scan. out8 (may be NULL) receives the current shares; in8 (may be NULL) replaces them (each clamped to [0.6, 1.5], renormalised
+ * to sum 8): a host layer that persists an index (rag_dpo_amd/collection.py) stores them with it and hands them back at load.
+ * Speed only, never results; they re-adapt if the values no longer fit the device. */
+int rdx_index_xcd_shares(rdx_index* h, double* out8, const double* in8);
+
 /* `SentenceTransformer.encode(..., normalize_embeddings=True)`'s last step
  * (reference src/utils/embedding_provider.py:139-145): out[i] = in[i] / max(||in[i]||_2, 1e-12). */
 int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space,

@@ -596,8 +596,14 @@ class Collection:
         os.makedirs(path, exist_ok=True)
         tmp = os.path.join(path, "collection.json.tmp")
         with open(tmp, "w", encoding="utf-8") as f:
-            json.dump({"name": self.name, "metadata": self.metadata, "dim": self._dim, "rows": rows,
-                       "format": self._snap_format if fmt is None else fmt, "gen": self._gen if gen is None else gen}, f)
+            hdr = {"name": self.name, "metadata": self.metadata, "dim": self._dim, "rows": rows,
+                   "format": self._snap_format if fmt is None else fmt, "gen": self._gen if gen is None else gen}
+            if self._engine is not None and hasattr(self._engine, "xcd_shares"):
+                try:   # what the scan has learned about this GPU's XCDs travels with the store (speed only; include/rdx.h)
+                    hdr["xcd_shares"] = [round(x, 5) for x in self._engine.xcd_shares()]
+                except Exception:
+                    pass
+            json.dump(hdr, f)
             f.flush()
             os.fsync(f.fileno())
         os.replace(tmp, os.path.join(path, "collection.json"))
@@ -737,6 +743,12 @@ class Collection:
                         f.truncate(f32_end)
         finally:
             self._replaying = False
+        sh = meta.get("xcd_shares")
+        if sh and self._engine is not None and hasattr(self._engine, "xcd_shares"):
+            try:
+                self._engine.xcd_shares(sh)
+            except Exception:      # (a header from another build: the shares are a hint, nothing more)
+                pass
 
 
 class PersistentClient:

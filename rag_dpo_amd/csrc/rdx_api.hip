@@ -400,6 +400,23 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     return RDX_OK;
 }
 
+extern "C" int rdx_index_xcd_shares(rdx_index* h, double* out8, const double* in8) {
+    if (!h) return fail(RDX_ERR_INVALID, "rdx_index_xcd_shares: null index");
+    std::lock_guard<std::mutex> lk(h->mu);
+    RDX_TRY(finish_pending(h, nullptr));
+    if (in8) {
+        double w[8], sum = 0;
+        for (int x = 0; x < 8; ++x) {
+            if (!(in8[x] > 0.0) || !(in8[x] < 100.0)) return fail(RDX_ERR_INVALID, "rdx_index_xcd_shares: shares must be positive finite numbers");
+            sum += (w[x] = std::min(1.5, std::max(0.6, in8[x])));
+        }
+        for (int x = 0; x < 8; ++x) h->xw[x] = w[x] * 8.0 / sum;
+    }
+    if (out8)
+        for (int x = 0; x < 8; ++x) out8[x] = h->xw[x];
+    return RDX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // ingest
 // ------------------------------------------------------------------------------------------------

@@ -66,6 +66,13 @@ class HipIndex:
     def set_option(self, name: str, value: int):
         L.check(self._lib.rdx_index_set_option(self._h, name.encode(), int(value)))
 
+    def xcd_shares(self, new=None):
+        """the main scan's per-XCD tile shares (include/rdx.h rdx_index_xcd_shares): returns the current 8 values; `new` replaces them"""
+        out = (ctypes.c_double * 8)()
+        inp = (ctypes.c_double * 8)(*[float(x) for x in new]) if new is not None else None
+        L.check(self._lib.rdx_index_xcd_shares(self._h, out, inp))
+        return list(out)
+
     # ---- helpers ----------------------------------------------------------------------------
     def _rows_arg(self, x, dtype=np.float32):
         """-> (pointer, n, space, keepalive)"""

@@ -27,6 +27,16 @@ def test_persistent_client_gpu(tmp_path):
     assert after["distances"] == before["distances"]      # stored rows reloaded verbatim (rdx_index_add_stored): same floats
     import numpy as np
     assert (np.asarray(col2.get(include=["embeddings"])["embeddings"]) == np.asarray(col.get(include=["embeddings"])["embeddings"])).all()
+    # what the scan has learned about this GPU's XCDs (speed only) travels with the store: set, persist, reopen, read back
+    sh = [1.04, 0.97, 1.0, 1.01, 0.99, 1.02, 0.98, 0.99]
+    got = col2._engine.xcd_shares(sh)
+    assert abs(sum(got) - 8.0) < 1e-9 and all(abs(a - b) < 1e-9 for a, b in zip(got, sh))
+    col2._write_header(col2._dir, col2._snap_rows)
+    col3 = PersistentClient(path=str(tmp_path / "db")).get_collection("rag_dpo_chunks")
+    assert all(abs(a - b) < 1e-4 for a, b in zip(col3._engine.xcd_shares(), sh))
+    assert col3.query(query_embeddings=q, n_results=50, where={"source": "CNIL"})["ids"] == before["ids"]
+    with pytest.raises(ValueError):
+        col3._engine.xcd_shares([1, 1, 1, 1, 1, 1, 1, float("nan")])
 
 
 def test_indexer_flow_gpu(tmp_path):
