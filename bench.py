@@ -181,8 +181,9 @@ def self_launch(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 20 for c4 / c5; 200 for c3, 500 for c1 / c2, whose steps are "
+                                                         "fractions of a millisecond: 20 of them end before the clocks have ramped)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps first (default: 3; 20 / 50 for the small workloads)")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=0, help="override the workload's total corpus rows")
     ap.add_argument("--batch", type=int, default=0)
@@ -238,6 +239,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
 
+    if args.steps <= 0:
+        args.steps = {"c1": 500, "c2": 500, "c3": 200}.get(args.workload, 20)
+    if args.warmup < 0:
+        args.warmup = {"c1": 50, "c2": 50, "c3": 20}.get(args.workload, 3)
     wl = dict(WORKLOADS[args.workload])
     if args.rows:
         wl["rows"] = args.rows

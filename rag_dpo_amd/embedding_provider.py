@@ -109,6 +109,7 @@ class EmbeddingProvider:
         self._dims: int = DEFAULT_DIMS
         import threading
         self._lock = threading.Lock()
+        self._pinned: dict = {}
         logger.info(f"EmbeddingProvider configured: {model_name} ({device}, {dtype}, batch={batch_size})")
 
     @property
@@ -169,6 +170,36 @@ class EmbeddingProvider:
     time_buckets = False               # True: CUDA events around every bucket's forward (last_encode_stats["buckets"][i]["ms"])
     last_encode_stats: Optional[dict] = None
 
+    def _h2d(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        """small host tensor -> device WITHOUT blocking the host: through a pinned staging buffer (one per name and shape, guarded
+        by an event: it is not overwritten before the copy that read it last has run). A pageable `.to(device)` is a synchronous copy:
+        it parks the host until everything enqueued on the stream so far — the previous batch's search — has finished, and the ~600
+        launches of the forward then start late (BASELINE config 5's pipeline: the encode of batch i+1 is issued behind search i)."""
+        if not str(self.device).startswith("cuda"):
+            return t.to(self.device)
+        key = (name, tuple(t.shape), t.dtype)
+        ent = self._pinned.get(key)
+        if ent is None:
+            if len(self._pinned) > 64:
+                self._pinned.clear()
+            ent = self._pinned[key] = [torch.empty(t.shape, dtype=t.dtype).pin_memory(), None]
+        buf, ev = ent
+        if ev is not None:
+            ev.synchronize()
+        buf.copy_(t)
+        d = buf.to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ent[1] = ev
+        return d
+
+    def _forward_cls(self, feed: dict) -> torch.Tensor:
+        """fp32 CLS rows of one padded bucket. (Round 3 also built a HIP-graph replay of this forward — ~700 launches that a busy host
+        issues more slowly (16 - 57 ms measured on this pool's boxes) than the GPU runs them (22 ms): captured per (rows, width)
+        shape, replayed with one launch. Alone it ran as fast as eager (27.8 ms per embed_device); enqueued behind a running search,
+        as BASELINE config 5's pipeline does, the replayed forward took 49 ms instead of 24. Removed: eager it stays.)"""
+        return self._model(**feed).last_hidden_state[:, 0].to(torch.float32)
+
     def _bucket_cuts(self, lens_desc: np.ndarray) -> List[int]:
         """row boundaries [0, ..., n] of the buckets for token counts sorted in descending order"""
         n = int(lens_desc.shape[0])
@@ -219,14 +250,13 @@ class EmbeddingProvider:
             extra = {k: v[by_len] for k, v in enc.items() if k not in ("input_ids", "attention_mask")}
             for lo, hi in zip(cuts[:-1], cuts[1:]):
                 w = int(lens_np[lo])                                        # the bucket's longest row (right padding: columns [:w])
-                feed = {"input_ids": ids[lo:hi, :w].to(self.device, non_blocking=True),
-                        "attention_mask": att[lo:hi, :w].to(self.device, non_blocking=True)}
-                feed.update({k: v[lo:hi, :w].to(self.device) for k, v in extra.items()})
+                feed = {"input_ids": self._h2d("ids", ids[lo:hi, :w]), "attention_mask": self._h2d("att", att[lo:hi, :w])}
+                feed.update({k: self._h2d(k, v[lo:hi, :w]) for k, v in extra.items()})
                 if self.time_buckets and on_gpu:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                hidden = self._model(**feed).last_hidden_state
-                out[torch.tensor(rows[lo:hi], device=self.device)] = hidden[:, 0].to(torch.float32)   # CLS pooling (BGE-M3 dense)
+                cls = self._forward_cls(feed)                                                   # CLS pooling (BGE-M3 dense)
+                out[self._h2d("rows", torch.tensor(rows[lo:hi], dtype=torch.int64))] = cls
                 if self.time_buckets and on_gpu:
                     e1.record()
                     events.append((len(stats["buckets"]), e0, e1))

@@ -23,3 +23,16 @@ print("forward, one padded batch of 1024  %.2f ms" % ms_fwd)
 ms_all, _ = timed(lambda: p.embed_device(texts))
 print("embed_device(1024 texts), batch_size %d: %.2f ms" % (b, ms_all))
 print("attn impl:", getattr(p._model.config, "_attn_implementation", None))
+def enqueue_only(n=10):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n):
+        p.embed_device(texts)
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    return (t1 - t) / n * 1e3, (t2 - t) / n * 1e3
+h, w = enqueue_only()
+print("embed_device: host returns after %.2f ms per call (enqueue), wall %.2f ms per call; last stats %s" % (h, w, {k: v for k, v in p.last_encode_stats.items() if k != "buckets"}))
+import cProfile, pstats, io
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5): p.embed_device(texts)
+pr.disable(); torch.cuda.synchronize()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(18); print(s.getvalue()[:3500])
