@@ -134,6 +134,7 @@ struct rdx_index {
 
     // options
     int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 1, force_bn = 0;
+    int small_scan = 1;      // option: k_scan_small (split-K over all rows) as the main scan of small launches
     int split_boot = 1;      // option: k_boot (K loop split over the waves) for the threshold bootstrap of small launches
     int fuse_finish = 1;     // option: the end-of-search work runs in the last block of the search's last kernel (0: its own launch k_finish)
     int spec_tau = 1;        // option: speculative scan threshold (rank < k of the sample, verified by k_refine)
@@ -368,6 +369,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "fuse_epilogue") h->fuse_epilogue = value != 0;
     else if (n == "fuse_finish") h->fuse_finish = value != 0;
     else if (n == "split_boot") h->split_boot = value != 0;
+    else if (n == "small_scan") h->small_scan = value != 0;
     else if (n == "spec_tau") {
         h->spec_tau = value != 0;
         h->spec_backoff = 0;
@@ -957,6 +959,9 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         int64_t boot_units = std::min<int64_t>(n_blocks32, n_sched * 8);
         if (boot_units > h->n_cu) boot_units = boot_units / h->n_cu * h->n_cu;
         const bool use_boot = h->split_boot && bn == BOOT_BN && nqt == 1 && boot_units <= 4 * (int64_t)h->n_cu;
+        // ... and the split-K main scan k_scan_small when the whole corpus is at most 32 such blocks per CU (scan_kernel.hpp K2c)
+        const bool use_small = h->small_scan && bn == BOOT_BN && nqt == 1 && h->ksteps <= 16 && n_streams == grid &&
+                               n_blocks32 <= 32 * (int64_t)h->n_cu && n_blocks32 >= grid;
         int boot_sets = 0;
         if (use_boot) {
             sample_rows = boot_units * 32;
@@ -1044,7 +1049,7 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         // proven threshold: 2E below the k-th sampled score — plus, when the sample was summed in another order than the main scan
         // sums (k_boot), twice the fp32 accumulation bound, so that the verification (c_k - 2E >= T, with c_k from the main
         // scan's sums) cannot fail on a rounding difference between the two orders
-        const float slack = h->two_e() + (use_boot ? 2.0f * (float)h->dim_pad * 1.1920929e-7f : 0.0f);
+        const float slack = h->two_e() + ((use_boot != use_small) ? 2.0f * (float)h->dim_pad * 1.1920929e-7f : 0.0f);
         hipLaunchKernelGGL(k_tau, dim3(nq_pad), dim3(256), 0, st, h->setmax.as<float>(), use_boot ? boot_sets : n_sets, n_sets_used, k_sel,
                            k_sel == k ? slack * std::ldexp(1.0f, 2 * h->scale_log2) : 0.0f, (int)nq, h->tau.as<float>());
         HIP_TRY(hipGetLastError());
@@ -1077,7 +1082,25 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
             RDX_TRY(h->wgt.ensure((size_t)grid * 16));
             p.wgt = h->wgt.as<unsigned long long>();
         }
-        RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, res, p, grid, st));
+        if (use_small) {
+            SmallScanParams sp = {};
+            sp.shadow = h->shadow;
+            sp.qshadow = h->qshadow.as<_Float16>();
+            sp.ksteps = h->ksteps;
+            sp.rows = h->rows;
+            sp.n_blocks32 = n_blocks32;
+            sp.allow = d_allow;
+            sp.tau = h->tau.as<float>();
+            sp.cntw = h->cntw.as<uint32_t>();
+            sp.cand = h->cand.as<uint2>();
+            sp.capw = capw;
+            sp.inv_scale2 = p.inv_scale2;
+            sp.wgt = p.wgt;
+            hipLaunchKernelGGL(k_scan_small, dim3((unsigned)grid), dim3(512), 0, st, sp);
+            HIP_TRY(hipGetLastError());
+        } else {
+            RDX_TRY(launch_scan_bn<EPI_EMIT>(h, bn, res, p, grid, st));
+        }
         p.use_xlo = 0;
         p.wgt = nullptr;
         mark(4);

@@ -820,6 +820,152 @@ __global__ __launch_bounds__(512) void k_boot(const BootParams p) {
     }
 }
 
+// K2c. Main scan of SMALL launches (<= 64 queries, <= 16 k-steps per row, at most a few hundred 32-row blocks per CU): k_boot's split-K
+// dataflow over ALL rows, with the emit epilogue. Why: the streaming kernel above deals whole 256-row tiles to 256 workgroups —
+// 100 k rows are 391 tiles, 1.53 per workgroup, i.e. TWO rounds of a 16-step pipeline for 1.5 rounds of work (and no finer unit
+// helps: 6 250 16-row blocks on 2 048 waves are 3.05 each, i.e. 4) — 41.9 us for a 25.6 us HBM stream at c2. Here a workgroup
+// takes a contiguous range of 32-row blocks (3 125 blocks / 256 = 12.2: the longest range is 13, 6 % over the mean), wave w owns
+// k-steps w and w + 8 of every block, its query fragments stay in registers for the whole launch (64 VGPRs, loaded once), the
+// next block's corpus fragments are requested before the current block is multiplied (64 KB in flight per CU), the eight partial
+// 32 x 64 tiles are summed through LDS slabs exactly as in k_boot (same order: the same coarse scores, bit for bit) and 256
+// threads compare the sums with the thresholds and append the hits (LDS counter per query, 8-byte store).
+struct SmallScanParams {
+    const _Float16* shadow;
+    const _Float16* qshadow;
+    int ksteps;
+    int64_t rows;
+    int64_t n_blocks32;
+    const uint32_t* allow;
+    const float* tau;          // [>= 64] accumulator units
+    uint32_t* cntw;            // [nq_pad][n_streams]
+    uint2* cand;               // [nq_pad][n_streams][capw]
+    uint32_t capw;
+    float inv_scale2;
+    unsigned long long* wgt;   // [grid][2] start / end stamps (NULL: not wanted)
+};
+__global__ __launch_bounds__(512) void k_scan_small(const SmallScanParams p) {
+    __shared__ __attribute__((aligned(16))) float slab[4][BOOT_BN * BOOT_LD];
+    __shared__ uint32_t lcnt[BOOT_BN];
+    __shared__ float tau_s[BOOT_BN];
+    const int stream = blockIdx.x, n_streams = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    if (p.wgt && threadIdx.x == 0) p.wgt[2 * blockIdx.x] = wall_clock64();
+    if (threadIdx.x < BOOT_BN) {
+        lcnt[threadIdx.x] = 0;
+        tau_s[threadIdx.x] = p.tau[threadIdx.x];
+    }
+    const int KS = p.ksteps;   // <= 16 (host)
+    constexpr int NB = BOOT_BN / 16;
+    const bool has0 = wave < KS, has1 = wave + 8 < KS;
+    const int ks0 = has0 ? wave : 0, ks1 = has1 ? wave + 8 : ks0;
+    const int64_t b0 = (int64_t)stream * p.n_blocks32 / n_streams, b1 = (int64_t)(stream + 1) * p.n_blocks32 / n_streams;
+    // this wave's query fragments, for the whole launch
+    half8 b[2][2][NB];
+    {
+        const char* q_base = reinterpret_cast<const char*>(p.qshadow);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const int r = n * 16 + l15;
+                    b[t][kk][n] = *reinterpret_cast<const half8*>(q_base + ((int64_t)(t ? ks1 : ks0) * 256 + r) * 128 + (((kk * 4 + lq) ^ ((r >> 1) & 7)) << 4));
+                }
+    }
+    const char* a_lane = reinterpret_cast<const char*>(p.shadow) + lane * 16;
+    const int64_t rb_bytes = (int64_t)KS * 4096;
+    auto load_a = [&](int64_t rb, half8 (&a)[2][4]) __attribute__((always_inline)) {
+        const char* base = a_lane + rb * rb_bytes;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[t][c] = *reinterpret_cast<const half8*>(base + (int64_t)(t ? ks1 : ks0) * 4096 + c * 1024);
+    };
+    float* mine = slab[wave & 3] + l15 * BOOT_LD + lq * 4;
+    // one block: multiply (fragments `a`), request the next block's fragments into `an` first
+    auto block = [&](int64_t rb, half8 (&a)[2][4], half8 (&an)[2][4]) __attribute__((always_inline)) {
+        load_a(rb + 1 < b1 ? rb + 1 : rb, an);   // (the last block re-reads itself: no branch around loads)
+        __builtin_amdgcn_sched_barrier(0);       // the requests leave before the MFMAs wait for the current fragments
+        f32x4 acc[2][NB];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t == 0 ? !has0 : !has1) continue;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][2 * kk], b[t][kk][n], acc[0][n], 0, 0, 0);
+                    acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][2 * kk + 1], b[t][kk][n], acc[1][n], 0, 0, 0);
+                }
+        }
+        if (wave >= 4) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) *reinterpret_cast<f32x4*>(mine + n * 16 * BOOT_LD + m * 16) = acc[m][n];
+        }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    f32x4* cell = reinterpret_cast<f32x4*>(mine + n * 16 * BOOT_LD + m * 16);
+                    const f32x4 o = *cell;
+                    *cell = f32x4{acc[m][n][0] + o[0], acc[m][n][1] + o[1], acc[m][n][2] + o[2], acc[m][n][3] + o[3]};
+                }
+        }
+        __syncthreads();
+        if (threadIdx.x < 4 * BOOT_BN) {
+            const int q = threadIdx.x & (BOOT_BN - 1), j = threadIdx.x / BOOT_BN;   // rows 8j .. 8j+7 of the block, query q
+            const int64_t row0 = rb * 32;
+            uint32_t ok = 0xffffffffu;
+            const int64_t left = p.rows - row0;
+            if (left < 32) ok = left <= 0 ? 0u : ((1u << left) - 1u);
+            if (p.allow && left > 0) ok &= p.allow[rb];
+            f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(slab[w] + q * BOOT_LD + j * 8);
+                const f32x4 y = *reinterpret_cast<const f32x4*>(slab[w] + q * BOOT_LD + j * 8 + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    lo[r] += x[r];
+                    hi[r] += y[r];
+                }
+            }
+            const float tq = tau_s[q];
+            const uint32_t seg0 = ((uint32_t)q * (uint32_t)n_streams + (uint32_t)stream) * p.capw;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float v = r < 4 ? lo[r & 3] : hi[r & 3];
+                if (v >= tq && ((ok >> (j * 8 + r)) & 1u)) {
+                    const uint32_t pos = atomicAdd(&lcnt[q], 1u);
+                    if (pos < p.capw) p.cand[seg0 + pos] = make_uint2(__float_as_uint(v * p.inv_scale2), (uint32_t)(row0 + j * 8 + r));
+                }
+            }
+        }
+        __syncthreads();   // the slabs are free for the next block
+    };
+    half8 a0[2][4], a1[2][4];
+    if (b0 < b1) load_a(b0, a0);
+    __syncthreads();       // lcnt / tau_s initialised
+    int64_t rb = b0;
+    for (; rb + 1 < b1; rb += 2) {
+        block(rb, a0, a1);
+        block(rb + 1, a1, a0);
+    }
+    if (rb < b1) block(rb, a0, a1);
+    if (threadIdx.x < BOOT_BN) p.cntw[(int64_t)threadIdx.x * n_streams + stream] = lcnt[threadIdx.x];
+    if (p.wgt && threadIdx.x == 0) p.wgt[2 * blockIdx.x + 1] = wall_clock64();
+}
+
 // K3a. tau[q] = (k-th largest of the query's set maxima) - 2E, in accumulator units; -inf if fewer than k
 // non-empty sets exist (then every allowed row is emitted). One block per query (padding queries: +inf).
 // Only the first n_sets_used sets (streams that scanned at least one tile) are looked at.

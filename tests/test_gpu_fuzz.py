@@ -57,6 +57,8 @@ def test_random_shapes_match_oracle(oracle):
             opts["split_boot"] = 0      # (default 1: split-K bootstrap kernel for <= 64 queries)
         if rng.random() < 0.2:
             opts["fuse_finish"] = 0     # (default 1: end-of-search work in the last block of the last kernel)
+        if rng.random() < 0.3:
+            opts["small_scan"] = 0      # (default 1: split-K main scan for <= 64 queries on small corpora)
         for name, v in opts.items():
             ix.set_option(name, v)
         es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, k, allow)

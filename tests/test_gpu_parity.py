@@ -504,6 +504,14 @@ def test_split_k_bootstrap(eng, oracle, d, n, b, k):
         st = _check(oracle, ix, corpus, q, k, expect_path=0)
         assert st["exact_queries"] == 0 and st["retried_queries"] == 0, (sb, st)
         _check(oracle, ix, corpus, q, k, allow, expect_path=0)
+        ix.set_option("small_scan", 0)                   # the streaming tile kernel as the main scan behind either bootstrap
+        st2 = _check(oracle, ix, corpus, q, k, expect_path=0)
+        _check(oracle, ix, corpus, q, k, allow, expect_path=0)
+        assert st2["exact_queries"] == 0 and st2["retried_queries"] == 0, (sb, st2)
+        ix.set_option("cand_cap", 8)                     # segments of 8 slots: overflow -> fallback passes, on both main scans
+        for ss in (1, 0):
+            ix.set_option("small_scan", ss)
+            _check(oracle, ix, corpus, q, k, expect_path=0)
         seen[sb] = st
         ix.close()
     assert seen[1]["sample_rows"] <= max(4 * 256 * 32, seen[0]["sample_rows"]), seen
