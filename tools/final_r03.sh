@@ -13,9 +13,10 @@ timeout -k 10 400 python3 bench.py --workload c5 --no-cpu > $O/c5.json 2> $O/c5.
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --enc-buckets 1 > $O/c5_one_forward.json 2> /dev/null || echo "bench c5 1 bucket failed"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --no-encode > $O/c5_noenc.json 2> /dev/null || echo "bench c5 noenc failed"
 timeout -k 10 400 python3 bench.py --workload c4 --no-cpu --set spec_tau=0 > $O/c4_nospec.json 2> /dev/null || echo "bench c4 nospec failed"
-timeout -k 10 400 python3 bench.py --workload c3 --no-cpu --steps 200 --warmup 20 --set spec_tau=0 > $O/c3_nospec.json 2> /dev/null || echo "bench c3 nospec failed"
-timeout -k 10 400 python3 bench.py --workload c2 --no-cpu --steps 300 --warmup 30 --set split_boot=0 > $O/c2_tile_bootstrap.json 2> /dev/null || echo "bench c2 sb0 failed"
-timeout -k 10 400 python3 bench.py --workload c1 --no-cpu --steps 300 --warmup 30 --set fuse_finish=0 > $O/c1_separate_finish.json 2> /dev/null || echo "bench c1 ff0 failed"
+timeout -k 10 400 python3 bench.py --workload c3 --no-cpu --set spec_tau=0 > $O/c3_nospec.json 2> /dev/null || echo "bench c3 nospec failed"
+timeout -k 10 400 python3 bench.py --workload c2 --no-cpu --set split_boot=0 > $O/c2_tile_bootstrap.json 2> /dev/null || echo "bench c2 sb0 failed"
+timeout -k 10 400 python3 bench.py --workload c1 --no-cpu --set fuse_finish=0 > $O/c1_separate_finish.json 2> /dev/null || echo "bench c1 ff0 failed"
+timeout -k 10 400 python3 bench.py --workload c2 --no-cpu --set small_scan=0 > $O/c2_tile_scan.json 2> /dev/null || echo "bench c2 ss0 failed"
 echo "variants done"
 timeout -k 10 600 bash tools/prof.sh r03 "--steps 8 --warmup 4 --no-cpu" || echo "prof failed $?"
 # per-launch durations of the main scan in the traced run: which launches an average covers (cold: the first 4, while the XCD shares
@@ -62,6 +63,7 @@ timeout -k 10 300 python3 bench.py --workload c4 --no-cpu --rows 1250000 --steps
 python3 tools/collection_latency.py 2>/dev/null | grep -v amdgpu > $O/collection_latency.txt
 RDX_BENCH_REHEARSAL=1 timeout -k 10 300 python3 bench.py --gpus 2 --rows 600000 --steps 3 --warmup 1 --check-merged > $O/rehearse2_selflaunch.json 2> $O/rehearse2.err; echo "self-launch rehearsal rc=$?"
 RDX_BENCH_REHEARSAL=1 timeout -k 10 300 python3 bench.py --gpus 3 --workload c3 --rows 300000 --steps 3 --warmup 1 --set cand_cap=8 > $O/rehearse3_overflow.json 2> $O/rehearse3.err; echo "overflow rehearsal rc=$?"
+timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.txt
 python3 - <<PY
 import json, glob
 for f in sorted(glob.glob("$O/*.json")):

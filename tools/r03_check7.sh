@@ -7,7 +7,7 @@ cd $R
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -5 $O/pytest.log
 [ $rc -eq 0 ] || exit 1
 for rnd in 1 2; do for ss in 1 0; do
-  timeout -k 10 300 python3 bench.py --workload c2 --no-cpu --set fuse_tau=$ss > $O/c2_ft${ss}_$rnd.json 2> /dev/null || echo "bench failed"
+  timeout -k 10 300 python3 bench.py --workload c2 --no-cpu --set small_scan=$ss > $O/c2_ss${ss}_$rnd.json 2> /dev/null || echo "bench failed"
 done; done
 timeout -k 10 300 python3 bench.py --workload c2 --no-cpu --profile-all > $O/c2_profall.json 2> /dev/null
 python3 - <<PY
