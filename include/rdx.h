@@ -117,6 +117,8 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * kernel (one 32-row block per workgroup, the k-steps dealt to its waves) instead of whole tiles on a few CUs;
  * "small_scan" 0/1 (default 1): the same searches on corpora of at most 32 such blocks per CU (262 K rows on 256 CUs) take their
  * main scan with the split-K kernel too (balanced in 32-row units instead of whole 256-row tiles);
+ * "half_boot" 0/1 (default 1): searches of 129..256 queries take their threshold sample as two 128-query tiles per sampled corpus
+ * tile (every CU busy, less data per k-step) instead of one 256-query tile on half the CUs;
  * "fuse_finish" 0/1 (default 1): the end-of-search work (counters and small results to pinned host memory) runs in the last
  * block of the search's last kernel instead of a launch of its own (both: speed only);
  * "retry" 0/1 (default 1): queries whose candidate

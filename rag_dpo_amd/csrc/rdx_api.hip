@@ -134,6 +134,7 @@ struct rdx_index {
 
     // options
     int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 1, force_bn = 0;
+    int half_boot = 1;       // option: 129..256 queries take their threshold sample as two 128-query tiles per sampled corpus tile
     int small_scan = 1;      // option: k_scan_small (split-K over all rows) as the main scan of small launches
     int split_boot = 1;      // option: k_boot (K loop split over the waves) for the threshold bootstrap of small launches
     int fuse_finish = 1;     // option: the end-of-search work runs in the last block of the search's last kernel (0: its own launch k_finish)
@@ -370,6 +371,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "fuse_finish") h->fuse_finish = value != 0;
     else if (n == "split_boot") h->split_boot = value != 0;
     else if (n == "small_scan") h->small_scan = value != 0;
+    else if (n == "half_boot") h->half_boot = value != 0;
     else if (n == "spec_tau") {
         h->spec_tau = value != 0;
         h->spec_backoff = 0;
@@ -935,6 +937,17 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         const bool res = bn == 64 && (size_t)h->ksteps * 8192 + 512 <= 160 * 1024 - 1024;
         // bootstrap sample: every div-th tile. More rows sampled = tighter tau = fewer hits; keep the expected hits
         // per query (~1.3 k rows/sample_rows) around 4000/... of the refine list and the sample >= max(64k, 8192) rows
+        // Bootstrap geometry. 129..256 queries run their main scan as ONE 256-query tile per workgroup, but their bootstrap samples
+        // ~130 tiles: as one tile per workgroup that is half the CUs working through 16 dependent k-steps of 64 KB each (36 us at
+        // c3). As TWO 128-query tiles per sampled tile every CU works, a k-step moves 48 KB and takes 1.4 instead of 2.25 us
+        // (DESIGN.md §10's table): option "half_boot" (default 1).
+        int bn_b = bn, nqt_b = nqt, ns_b = n_streams;
+        if (h->half_boot && bn == 256 && nqt == 1) {
+            bn_b = 128;
+            nqt_b = 2;
+            ns_b = 8 * (wpx / 2);
+        }
+        const int n_sets_b = ns_b * SETS_PER_STREAM;
         const int64_t want_rows = std::max<int64_t>(64 * (int64_t)k, 8192);
         int div = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(h->sample_div, h->rows / want_rows), 3000 / std::max(k, 1)));
         if (depth > 0) div = std::max(1, div / 8);   // second chance: 8x denser sample -> a threshold that sees the cluster
@@ -942,8 +955,8 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         // whole rounds only: the bootstrap takes as long as its busiest stream, so 77 tiles on 64 streams cost two tiles' time for
         // 1.2 tiles' worth of threshold (a 1.25 M-row shard at B = 1024: 53 -> 27 us of a 2.26 ms search); thin the sample to the
         // last full round instead, as long as it keeps the rows asked for above
-        if (n_sched > n_streams && n_sched % n_streams != 0) {
-            const int64_t full = n_sched / n_streams * n_streams;
+        if (n_sched > ns_b && n_sched % ns_b != 0) {
+            const int64_t full = n_sched / ns_b * ns_b;
             const int div2 = (int)((n_tiles + full - 1) / full);
             if ((n_tiles + div2 - 1) / div2 * 256 >= want_rows) {
                 div = div2;
@@ -951,7 +964,7 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
             }
         }
         sample_rows = n_sched * 256;
-        int n_sets_used = (int)std::min<int64_t>(n_streams, n_sched) * SETS_PER_STREAM;
+        int n_sets_used = (int)std::min<int64_t>(ns_b, n_sched) * SETS_PER_STREAM;
         // Small launches (<= 64 queries and a sample of at most four 32-row blocks per CU): the split-K bootstrap k_boot — one
         // 32-row block per workgroup, the k-steps dealt to the waves — instead of a few whole tiles of 16 dependent k-steps on
         // a few CUs (scan_kernel.hpp K2b). Whole rounds of the CUs when more than one.
@@ -980,7 +993,7 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         RDX_TRY(h->tau.ensure((size_t)nq_pad * 4));
         RDX_TRY(h->cntw.ensure((size_t)nq_pad * n_streams * 4));
         RDX_TRY(h->cand.ensure((size_t)nq_pad * n_streams * capw * 8));
-        RDX_TRY(h->setmax.ensure((size_t)nq_pad * std::max(n_sets, boot_sets) * 4));
+        RDX_TRY(h->setmax.ensure((size_t)nq_pad * std::max(std::max(n_sets, n_sets_b), boot_sets) * 4));
 
         ScanParams p = {};
         p.shadow = h->shadow;
@@ -1020,8 +1033,12 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
             hipLaunchKernelGGL(k_boot, dim3((unsigned)boot_units), dim3(512), 0, st, bp);
             HIP_TRY(hipGetLastError());
         } else {
-            p.tile_stride = div;
-            RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn, res, p, grid, st));
+            ScanParams pb = p;
+            pb.tile_stride = div;
+            pb.nqt = nqt_b;
+            pb.n_sets = n_sets_b;
+            pb.sib = nullptr;
+            RDX_TRY(launch_scan_bn<EPI_SETMAX>(h, bn_b, bn_b == bn ? res : false, pb, grid, st));
         }
         mark(2);
         // Speculative threshold. The provable threshold is the k-th largest sampled score: k/S of the sample's
@@ -1050,7 +1067,7 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         // sums (k_boot), twice the fp32 accumulation bound, so that the verification (c_k - 2E >= T, with c_k from the main
         // scan's sums) cannot fail on a rounding difference between the two orders
         const float slack = h->two_e() + ((use_boot != use_small) ? 2.0f * (float)h->dim_pad * 1.1920929e-7f : 0.0f);
-        hipLaunchKernelGGL(k_tau, dim3(nq_pad), dim3(256), 0, st, h->setmax.as<float>(), use_boot ? boot_sets : n_sets, n_sets_used, k_sel,
+        hipLaunchKernelGGL(k_tau, dim3(nq_pad), dim3(256), 0, st, h->setmax.as<float>(), use_boot ? boot_sets : n_sets_b, n_sets_used, k_sel,
                            k_sel == k ? slack * std::ldexp(1.0f, 2 * h->scale_log2) : 0.0f, (int)nq, h->tau.as<float>());
         HIP_TRY(hipGetLastError());
         mark(3);

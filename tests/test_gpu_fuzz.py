@@ -59,6 +59,8 @@ def test_random_shapes_match_oracle(oracle):
             opts["fuse_finish"] = 0     # (default 1: end-of-search work in the last block of the last kernel)
         if rng.random() < 0.3:
             opts["small_scan"] = 0      # (default 1: split-K main scan for <= 64 queries on small corpora)
+        if rng.random() < 0.3:
+            opts["half_boot"] = 0       # (default 1: 129..256 queries sample their threshold as two 128-query tiles per corpus tile)
         for name, v in opts.items():
             ix.set_option(name, v)
         es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, k, allow)

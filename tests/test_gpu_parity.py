@@ -161,6 +161,21 @@ def test_search_in_two_halves(eng, oracle):
     ix.close()
 
 
+@pytest.mark.parametrize("b", [129, 200, 256])
+def test_half_tile_bootstrap(eng, oracle, b):
+    """option half_boot (default 1): 129..256 queries sample their threshold with the 128-query kernel as two query tiles per sampled
+    corpus tile; same answers as with the one-tile bootstrap, with a bitmap too"""
+    corpus = synth.make_corpus(90_000, 256)
+    q = synth.make_queries(b, 256, corpus)
+    allow = np.random.default_rng(b).random(corpus.shape[0]) < 0.5
+    for hb in (1, 0):
+        ix = _index(eng, corpus, half_boot=hb)
+        st = _check(oracle, ix, corpus, q, 20, expect_path=0)
+        assert st["exact_queries"] == 0 and st["retried_queries"] == 0, (hb, st)
+        _check(oracle, ix, corpus, q, 20, allow, expect_path=0)
+        ix.close()
+
+
 @pytest.mark.parametrize("fused", [1, 0])
 def test_fused_epilogue_variant(eng, oracle, fused):
     """option fuse_epilogue (default 1): the B > 128 main scan whose emit check rides in the next tile's first k-step — several
