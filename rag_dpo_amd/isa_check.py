@@ -23,7 +23,10 @@ import sys
 from typing import Dict, List, Tuple
 
 VM_PREFIXES = ("global_load", "global_store", "global_atomic", "buffer_load", "buffer_store", "buffer_atomic", "flat_load",
-               "flat_store", "flat_atomic", "scratch_load", "scratch_store", "tbuffer_load", "tbuffer_store")
+               "flat_store", "flat_atomic", "scratch_load", "scratch_store", "tbuffer_load", "tbuffer_store",
+               # cache maintenance behind agent / system-scope fences: counted in vmcnt as well (MI355X_MICROARCH.md: an
+               # s_waitcnt vmcnt(0) behind a buffer_inv waits for it) — leaving them out would make the model retire loads too early
+               "buffer_inv", "buffer_wbl2", "buffer_wbinvl1", "global_inv", "global_wb")
 _V1 = re.compile(r"\bv(\d+)\b")
 _VR = re.compile(r"\bv\[(\d+):(\d+)\]")
 _LABEL = re.compile(r"^(\.L[A-Za-z0-9_$.]+):")
