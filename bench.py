@@ -373,57 +373,61 @@ def main():
     #     is checksummed and the checksums compared: all ranks hold the same answer. (3) what RCCL ran on. (4) where a step's
     #     time goes on rank 0 (events around the pieces, in a separate short leg: never inside the timed region).
     dist_check, rccl_info, step_breakdown = None, None, None
-    if (world > 1 or args.force_dist):
-        props = torch.cuda.get_device_properties(device)
-        mine = {"rank": rank, "device_index": local_rank, "name": props.name, "gcnArch": getattr(props, "gcnArchName", "?").split(":")[0]}
-        infos = [None] * world
-        dist.all_gather_object(infos, mine)
-        try:
-            ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if not rehearsal else None
-        except Exception:
-            ver = None
-        rccl_info = {"world": world, "backend": dist.get_backend(), "rccl_version": ver, "devices": infos,
-                     "collectives_per_step": "1 all_gather_into_tensor of the packed partials (rows|scores|counts|flags), nothing else",
-                     "queries": "rank 0's batch, broadcast once before the timed region"}
-        if not args.no_check:
-            nchk = min(B, 32)
-            qs = queries[:nchk].contiguous()
-            m_s, m_r, m_c = [t.clone() for t in searcher.search(qs, k)]
-            full_s, full_r, full_c = [t.clone() for t in searcher.search(queries, k)]     # the whole batch, for the checksum
-            shard.index.set_option("force_exact", 1)
-            x_s, x_r, x_c = [t.clone() for t in searcher.search(qs, k)]
-            shard.index.set_option("force_exact", 0)
-            torch.cuda.synchronize(device)
-            exact_equal = bool((x_r == m_r).all() and (x_s == m_s).all() and (x_c == m_c).all())
-            prefix_equal = bool((full_r[:nchk] == m_r).all() and (full_s[:nchk] == m_s).all())   # a query's answer does not depend on its batch
-            # checksum of everything this rank would hand to a caller: rows, score BITS, counts (wrapping int64 sums + a weighted one)
-            w = torch.arange(1, full_r.numel() + 1, device=full_r.device, dtype=torch.int64)
-            bits = full_s.view(torch.int32).to(torch.int64)
-            ck = torch.stack([full_r.sum(), (full_r.flatten() * w).sum(), bits.sum(), (bits.flatten() * w).sum(),
-                              full_c.to(torch.int64).sum(), torch.tensor(int(exact_equal and prefix_equal), device=full_r.device)])
-            ck_h = ck.cpu() if rehearsal else ck
-            allck = torch.empty(world * ck.numel(), dtype=torch.int64, device=ck_h.device)   # (flat: gloo refuses a 2-D output)
-            dist.all_gather_into_tensor(allck, ck_h)
-            allck = allck.cpu().view(world, ck.numel())
-            dist_check = {"queries_exact_leg": nchk,
-                          "per_shard_exact_scan_merged_equals_mfma_merged": bool(allck[:, 5].all().item()),
-                          "merged_identical_on_all_ranks": bool((allck[:, :5] == allck[0, :5]).all().item()),
-                          "checksum_rank0": [int(v) for v in allck[0, :5]],
-                          "exchanges_per_search": "1 (a second one only when the merged flags word says a rank re-ran overflowed queries)"}
-            # step breakdown on rank 0: search kernels / all-gather / merge, events on the stream, min(steps, 10) extra steps
-            searcher.time_events = True
-            nb = max(3, min(args.steps, 10))
-            ex0 = searcher.exchanges
-            for _ in range(nb):
-                searcher.search(queries, k)
-            barrier()
-            bd = searcher.breakdown(last=nb)
-            searcher.time_events = False
-            if bd is not None:
-                step_breakdown = {"steps": nb, "scan_ms": round(bd[0], 4), "exchange_ms": round(bd[1], 4), "merge_ms": round(bd[2], 4),
-                                  "exchanges": searcher.exchanges - ex0,
-                                  "note": "rank 0, torch events on the search's stream: everything librdx enqueues for the shard's search "
-                                          "(K1 .. k_finish) | all_gather_into_tensor | rdx_merge_topk_packed; a separate leg after the timed region"}
+    try:
+        if (world > 1 or args.force_dist):
+            props = torch.cuda.get_device_properties(device)
+            mine = {"rank": rank, "device_index": local_rank, "name": props.name, "gcnArch": getattr(props, "gcnArchName", "?").split(":")[0]}
+            infos = [None] * world
+            dist.all_gather_object(infos, mine)
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if not rehearsal else None
+            except Exception:
+                ver = None
+            rccl_info = {"world": world, "backend": dist.get_backend(), "rccl_version": ver, "devices": infos,
+                         "collectives_per_step": "1 all_gather_into_tensor of the packed partials (rows|scores|counts|flags), nothing else",
+                         "queries": "rank 0's batch, broadcast once before the timed region"}
+            if not args.no_check:
+                nchk = min(B, 32)
+                qs = queries[:nchk].contiguous()
+                m_s, m_r, m_c = [t.clone() for t in searcher.search(qs, k)]
+                full_s, full_r, full_c = [t.clone() for t in searcher.search(queries, k)]     # the whole batch, for the checksum
+                shard.index.set_option("force_exact", 1)
+                x_s, x_r, x_c = [t.clone() for t in searcher.search(qs, k)]
+                shard.index.set_option("force_exact", 0)
+                torch.cuda.synchronize(device)
+                exact_equal = bool((x_r == m_r).all() and (x_s == m_s).all() and (x_c == m_c).all())
+                prefix_equal = bool((full_r[:nchk] == m_r).all() and (full_s[:nchk] == m_s).all())   # a query's answer does not depend on its batch
+                # checksum of everything this rank would hand to a caller: rows, score BITS, counts (wrapping int64 sums + a weighted one)
+                w = torch.arange(1, full_r.numel() + 1, device=full_r.device, dtype=torch.int64)
+                bits = full_s.view(torch.int32).to(torch.int64)
+                ck = torch.stack([full_r.sum(), (full_r.flatten() * w).sum(), bits.sum(), (bits.flatten() * w).sum(),
+                                  full_c.to(torch.int64).sum(), torch.tensor(int(exact_equal and prefix_equal), device=full_r.device)])
+                ck_h = ck.cpu() if rehearsal else ck
+                allck = torch.empty(world * ck.numel(), dtype=torch.int64, device=ck_h.device)   # (flat: gloo refuses a 2-D output)
+                dist.all_gather_into_tensor(allck, ck_h)
+                allck = allck.cpu().view(world, ck.numel())
+                dist_check = {"queries_exact_leg": nchk,
+                              "per_shard_exact_scan_merged_equals_mfma_merged": bool(allck[:, 5].all().item()),
+                              "merged_identical_on_all_ranks": bool((allck[:, :5] == allck[0, :5]).all().item()),
+                              "checksum_rank0": [int(v) for v in allck[0, :5]],
+                              "exchanges_per_search": "1 (a second one only when the merged flags word says a rank re-ran overflowed queries)"}
+                # step breakdown on rank 0: search kernels / all-gather / merge, events on the stream, min(steps, 10) extra steps
+                searcher.time_events = True
+                nb = max(3, min(args.steps, 10))
+                ex0 = searcher.exchanges
+                for _ in range(nb):
+                    searcher.search(queries, k)
+                barrier()
+                bd = searcher.breakdown(last=nb)
+                searcher.time_events = False
+                if bd is not None:
+                    step_breakdown = {"steps": nb, "scan_ms": round(bd[0], 4), "exchange_ms": round(bd[1], 4), "merge_ms": round(bd[2], 4),
+                                      "exchanges": searcher.exchanges - ex0,
+                                      "note": "rank 0, torch events on the search's stream: everything librdx enqueues for the shard's search "
+                                              "(K1 .. k_finish) | all_gather_into_tensor | rdx_merge_topk_packed; a separate leg after the timed region"}
+    except Exception as e:   # the checker legs must never take the measured number down with them (every rank runs the same code
+        log(f"[rank {rank}] distributed check leg failed: {e!r}")   # on the same data: a failure here is the same failure on every rank)
+        dist_check = {"error": repr(e)}
 
     merged_ok = None
     if args.check_merged and world > 1:
