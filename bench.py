@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
     ap.add_argument("--no-encode", action="store_true", help="c5: leave the BGE-M3 query encode out of the step")
     ap.add_argument("--enc-buckets", type=int, default=4, help="c5: most length buckets (forwards) per encoded batch; 1 = one forward padded to the longest text")
+    ap.add_argument("--enc-module-forward", action="store_true", help="c5: the checkpoint's module-by-module forward over the padded batch instead of the packed forward")
     ap.add_argument("--no-overlap", action="store_true", help="c5: encode then search on one stream (no pipelining of batch i+1's encode with batch i's search)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="developer: rdx_index_set_option before the run")
     ap.add_argument("--fp32-master", action="store_true", help="c5: keep the normalised fp32 rows as the exact copy (6 instead of 4 B/element)")
@@ -287,7 +288,9 @@ def main():
     if encode:
         from rag_dpo_amd.embedding_provider import EmbeddingProvider
         provider = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device=str(device), dtype=torch.float16,
-                                     batch_size=int(os.environ.get("RDX_ENC_BATCH", "1024"))).load()
+                                     batch_size=int(os.environ.get("RDX_ENC_BATCH", "1024")))
+        provider.packed_forward = not args.enc_module_forward
+        provider.load()
         provider.max_buckets = max(1, args.enc_buckets)
         texts = synth.query_texts(B)
 
@@ -451,6 +454,8 @@ def main():
         enc_stats = {"tokens_real": es["tokens_real"], "tokens_padded": es["tokens_padded"],
                      "tokens_real_over_padded": es["real_over_padded"],
                      "tokens_padded_if_one_forward": es["tokens_padded_one_width"], "buckets": es["buckets"],
+                     "forward": ("packed: token-wise layers over the real tokens only, padding only around the attention, one GEMM for Q/K/V (one forward per batch)"
+                                 if provider._packed is not None else "the checkpoint's module forward over the padded batch"),
                      "rule": "token-count-sorted rows cut into <= %d buckets (multiples of %d rows), each forwarded at its own width" % (provider.max_buckets, provider.bucket_granule)}
     out = None
     if rank == 0:

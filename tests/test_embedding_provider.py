@@ -162,7 +162,9 @@ def test_length_buckets_change_padding_not_values():
     words = [f"w{i}" for i in range(300)]
     texts = [" ".join(rng.choice(words, size=int(n))) for n in rng.integers(3, 60, size=300)]
     texts[17] = " ".join(rng.choice(words, size=200))              # one long outlier: the reason one width is wasteful
-    p = EmbeddingProvider(model_name="random-init:tiny", device="cpu", dtype=torch.float32, batch_size=512).load()
+    p = EmbeddingProvider(model_name="random-init:tiny", device="cpu", dtype=torch.float32, batch_size=512)
+    p.packed_forward = False                                      # (the module-by-module forward: the one that pays for padding)
+    p.load()
     p.max_buckets, p.bucket_granule, p.bucket_overhead_tokens = 1, 64, 0
     one = p._encode_raw(texts)
     s1 = dict(p.last_encode_stats)
@@ -182,3 +184,24 @@ def test_length_buckets_change_padding_not_values():
     cost = lambda c: sum((b - a) * lens[a] + 500 for a, b in zip(c[:-1], c[1:]))
     cands = [[0, 256]] + [[0, i, 256] for i in (64, 128, 192)] + [[0, i, j, 256] for i in (64, 128) for j in (128, 192) if j > i]
     assert cuts[0] == 0 and cuts[-1] == 256 and cost(cuts) == min(cost(c) for c in cands)
+
+
+def test_packed_forward_equals_the_module_forward():
+    """_PackedEncoder (token-wise layers over the real tokens only, Q/K/V scattered into the padded layout just for the attention,
+    one GEMM for the three projections) against `XLMRobertaModel.forward` on the same weights: the same CLS rows, texts of 1 to
+    200 tokens in one batch, and through embed_device()'s batching"""
+    import torch
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    rng = np.random.default_rng(9)
+    words = [f"w{i}" for i in range(300)]
+    texts = [" ".join(rng.choice(words, size=int(n))) for n in rng.integers(1, 60, size=120)] + [" ".join(rng.choice(words, size=200)), "w1"]
+    ref = EmbeddingProvider(model_name="random-init:tiny", device="cpu", dtype=torch.float32, batch_size=512)
+    ref.packed_forward = False
+    ref.load()
+    fast = EmbeddingProvider(model_name="random-init:tiny", device="cpu", dtype=torch.float32, batch_size=512).load()
+    assert fast._packed is not None and ref._packed is None
+    a, b = ref._encode_raw(texts), fast._encode_raw(texts)
+    assert torch.allclose(a, b, atol=2e-5, rtol=1e-5), float((a - b).abs().max())
+    assert len(fast.last_encode_stats["buckets"]) == 1            # padding costs the attention only: one forward
+    fast.batch_size = 50                                          # several batches
+    assert torch.allclose(fast._encode_raw(texts), a, atol=2e-5, rtol=1e-5)
