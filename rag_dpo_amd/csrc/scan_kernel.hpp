@@ -43,10 +43,27 @@
 
 namespace rdx {
 
-#if defined(RDX_ABL_NOA) || defined(RDX_ABL_NOB) || defined(RDX_ABL_NOEMIT)
+#if defined(RDX_ABL_NOA) || defined(RDX_ABL_NOB) || defined(RDX_ABL_NOEMIT) || defined(RDX_ABL_HALFB) || defined(RDX_ABL_DBLA)
 #define RDX_EMIT_ON false   // ablation builds never emit (their scores are meaningless)
 #else
 #define RDX_EMIT_ON true
+#endif
+// Developer ablations that price a 4 x 2 wave layout (each wave 64 rows x 128 queries) WITHOUT building it — timing only, scores are
+// garbage (tools/ab_lib.py). At BN = 256, ring mode:
+//   RDX_ABL_HALFB  half the query-fragment reads: odd MFMA groups reuse the even group's fragments (16 instead of 32 ds_read_b128 per
+//                  wave and k-step, what a wave with 128 queries would read);
+//   RDX_ABL_DBLA   twice the corpus loads: waves w and w + 4 both fetch the two 32-row blocks 2(w & 3), 2(w & 3) + 1 (8 instead of 4
+//                  global_load_dwordx4 per wave and k-step, every line requested by two waves of the CU; the second block lands in the
+//                  first one's registers — a real build needs 32 more).
+#ifdef RDX_ABL_HALFB
+#define RDX_HALFB 1
+#else
+#define RDX_HALFB 0
+#endif
+#ifdef RDX_ABL_DBLA
+#define RDX_DBLA 1
+#else
+#define RDX_DBLA 0
 #endif
 
 #ifndef RDX_PD256
@@ -160,7 +177,10 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     // fabric's bandwidth, so this variant (SIBT) is selected only when option "sib_sync" is set.
     constexpr bool SIB = SIBT && EPI == EPI_EMIT && !RES && BN == 256;
     constexpr int SIBN = SIB ? 2 : 0;                  // its vector-memory operations per wave and k-step: one store, one load
-    constexpr int V = 4 + (RES ? 0 : NPB) + SIBN;      // vector-memory operations a wave issues per k-step
+    constexpr bool DBLA = RDX_DBLA && BN == 256 && !RES;   // (ablation, see above)
+    constexpr bool HALFB = RDX_HALFB && BN == 256 && !RES;
+    constexpr int NA = DBLA ? 8 : 4;                   // corpus loads per wave and k-step
+    constexpr int V = NA + (RES ? 0 : NPB) + SIBN;     // vector-memory operations a wave issues per k-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // ---- which stream / query tile am I (XCD-aware: blocks with equal blockIdx % 8 share an L2) ----
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
             return reinterpret_cast<const char*>(p.shadow) + (bad ? (int64_t)0 : off);
         }
 #endif
-        return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096;   // wave-uniform
+        return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + (DBLA ? (wave & 3) * 2 : wave)) * rb_bytes + (int64_t)ks_i * 4096;   // wave-uniform
     };
 
     // v_mfma_f32_16x16x32_f16: the wave's 32 rows are two 16-row blocks m, the queries NB16 blocks of 16; C layout
@@ -377,6 +397,13 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
             gload16<NT_A, 1024>(af[1], sj, lane16);
             gload16<NT_A, 2048>(af[2], sj, lane16);
             gload16<NT_A, 3072>(af[3], sj, lane16);
+            if constexpr (DBLA) {
+                const char* sj2 = sj + rb_bytes;
+                gload16<NT_A, 0>(af[0], sj2, lane16);
+                gload16<NT_A, 1024>(af[1], sj2, lane16);
+                gload16<NT_A, 2048>(af[2], sj2, lane16);
+                gload16<NT_A, 3072>(af[3], sj2, lane16);
+            }
         };
         first_load(a0, 0);
         first_load(a1, 1);
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     if ((RDX_HALF_STAGGER && (g == 0 || g == NG / 2)) || (!RDX_HALF_STAGGER && g == BAR_G)) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (here) {
-                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + SIBN + V) : "memory");
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + SIBN + V) : "memory");
                             __builtin_amdgcn_s_barrier();
 #if !defined(RDX_ABL_NOB)
                             if (RDX_HALF_STAGGER || !RDX_DMA_STAGGER || !dma_late) issue_b(ksb, (slot_c + 3) & 3);
@@ -526,16 +553,20 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                    // (HALFB: the even group's fragment, made a new value for the compiler — equal operands on equal accumulators would be merged)
+                    if (HALFB && (g & 1)) asm volatile("" : "+v"(bf[(g & ~1) % NBUF][j]));
                     if (RDX_ZERO_C && FUSE && kk == 0) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bf[g % NBUF][j], zero4, 0, 0, 0);
-                    else acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk], bf[g % NBUF][j], acc[0][n], 0, 0, 0);
+                    else acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk], bf[(HALFB ? (g & ~1) : g) % NBUF][j], acc[0][n], 0, 0, 0);
                     if (j == 0) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (g + PD < NG) load_group(st, g + PD, bf[(g + PD) % NBUF]);
-                        else load_group(stn, g + PD - NG, bf[(g + PD) % NBUF]);   // first groups of step s+1 (after the mid barrier)
+                        if (!HALFB || ((g + PD) & 1) == 0) {
+                            if (g + PD < NG) load_group(st, g + PD, bf[(g + PD) % NBUF]);
+                            else load_group(stn, g + PD - NG, bf[(g + PD) % NBUF]);   // first groups of step s+1 (after the mid barrier)
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if (RDX_ZERO_C && FUSE && kk == 0) acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bf[g % NBUF][j], zero4, 0, 0, 0);
-                    else acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk + 1], bf[g % NBUF][j], acc[1][n], 0, 0, 0);
+                    else acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * kk + 1], bf[(HALFB ? (g & ~1) : g) % NBUF][j], acc[1][n], 0, 0, 0);
                 }
                 if ((g % GPK) == GPK - 1) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -546,9 +577,17 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
                     if (kk == 0) {
                         gload16<NT_A, 0>(af[0], an, lane16);
                         gload16<NT_A, 1024>(af[1], an, lane16);
+                        if constexpr (DBLA) {
+                            gload16<NT_A, 0>(af[0], an + rb_bytes, lane16);
+                            gload16<NT_A, 1024>(af[1], an + rb_bytes, lane16);
+                        }
                     } else {
                         gload16<NT_A, 2048>(af[2], an, lane16);
                         gload16<NT_A, 3072>(af[3], an, lane16);
+                        if constexpr (DBLA) {
+                            gload16<NT_A, 2048>(af[2], an + rb_bytes, lane16);
+                            gload16<NT_A, 3072>(af[3], an + rb_bytes, lane16);
+                        }
                     }
                     if constexpr (SIB) {
                         if (kk == 0) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(poll) : "v"(zero_off), "s"(uniform_ptr(sib_word)) : "memory");
