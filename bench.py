@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
     ap.add_argument("--no-encode", action="store_true", help="c5: leave the BGE-M3 query encode out of the step")
     ap.add_argument("--enc-buckets", type=int, default=4, help="c5: most length buckets (forwards) per encoded batch; 1 = one forward padded to the longest text")
+    ap.add_argument("--enc-torch-ops", action="store_true", help="c5: the packed forward on torch operations only (without librdx's attention and add + LayerNorm kernels)")
     ap.add_argument("--enc-module-forward", action="store_true", help="c5: the checkpoint's module-by-module forward over the padded batch instead of the packed forward")
     ap.add_argument("--no-overlap", action="store_true", help="c5: encode then search on one stream (no pipelining of batch i+1's encode with batch i's search)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=INT", help="developer: rdx_index_set_option before the run")
@@ -290,6 +291,8 @@ def main():
         provider = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device=str(device), dtype=torch.float16,
                                      batch_size=int(os.environ.get("RDX_ENC_BATCH", "1024")))
         provider.packed_forward = not args.enc_module_forward
+        if args.enc_torch_ops:
+            provider.fused_kernels = False
         provider.load()
         provider.max_buckets = max(1, args.enc_buckets)
         texts = synth.query_texts(B)
@@ -454,8 +457,10 @@ def main():
         enc_stats = {"tokens_real": es["tokens_real"], "tokens_padded": es["tokens_padded"],
                      "tokens_real_over_padded": es["real_over_padded"],
                      "tokens_padded_if_one_forward": es["tokens_padded_one_width"], "buckets": es["buckets"],
-                     "forward": ("packed: token-wise layers over the real tokens only, padding only around the attention, one GEMM for Q/K/V (one forward per batch)"
-                                 if provider._packed is not None else "the checkpoint's module forward over the padded batch"),
+                     "forward": ("the checkpoint's module forward over the padded batch" if provider._packed is None else
+                                 "packed + librdx kernels: every layer over the real tokens only (no padding anywhere), one GEMM for Q/K/V, rdx_enc_attention_f16, "
+                                 "rdx_enc_add_layernorm_f16; GEMMs and GELU are torch's" if provider._packed.fused else
+                                 "packed, torch operations: token-wise layers over the real tokens only, padding only around the attention, one GEMM for Q/K/V"),
                      "rule": "token-count-sorted rows cut into <= %d buckets (multiples of %d rows), each forwarded at its own width" % (provider.max_buckets, provider.bucket_granule)}
     out = None
     if rank == 0:

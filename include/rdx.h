@@ -137,6 +137,22 @@ int rdx_index_xcd_shares(rdx_index* h, double* out8, const double* in8);
 int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space,
                      void* stream);
 
+/* Two fused kernels for the memory-bound parts of the query encoder's forward — what `SentenceTransformer.encode` runs on the
+ * GPU in front of that normalisation (reference src/utils/embedding_provider.py:118-147; the GEMMs stay the BLAS library's, driven
+ * from rag_dpo_amd/embedding_provider.py). fp16 device pointers, 16-byte aligned; enqueued on `stream`, nothing is synchronised.
+ *
+ * rdx_enc_attention_f16: self-attention over PACKED tokens (no padding). qkv [n_tokens][3*heads*head_dim]: per token its query,
+ *   key and value rows (heads x head_dim each, head-major); token t belongs to the text whose tokens are
+ *   tok_first[t] .. tok_first[t] + tok_len[t] - 1 (tok_len >= 1) and attends to exactly those. ctx [n_tokens][heads*head_dim] =
+ *   softmax(q k^T * scale) v per head, soft-max and accumulation in fp32. head_dim must be 64. Meant for short texts
+ *   (questions): the work per token grows with its text's length.
+ * rdx_enc_add_layernorm_f16: out[r] = LayerNorm(a[r] + b[r]) * gamma + beta over rows of `hidden` halves (512, 1024, 1536 or
+ *   2048; biased variance, fp32 statistics, the sum rounded to fp16 first — what an fp16 add followed by LayerNorm computes). */
+int rdx_enc_attention_f16(int device, const void* qkv, const int32_t* tok_first, const int32_t* tok_len,
+                          int64_t n_tokens, int heads, int head_dim, float scale, void* ctx, void* stream);
+int rdx_enc_add_layernorm_f16(int device, const void* a, const void* b, const void* gamma, const void* beta,
+                              float eps, int64_t rows, int hidden, void* out, void* stream);
+
 /* `collection.query(query_embeddings=, n_results=k, where=)` (reference
  * src/rag/retriever.py:215-220,380-385; create_chromadb_index.py:405-408,435-439).
  *   queries     [nq][dim] raw fp32 (normalised on the device like corpus rows)

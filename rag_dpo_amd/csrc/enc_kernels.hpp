@@ -1,0 +1,168 @@
+// enc_kernels.hpp — E1/E2: the two memory-bound pieces of the query encoder's forward that PyTorch runs as several kernels each.
+// (`SentenceTransformer.encode`, reference src/utils/embedding_provider.py:139-145; SURVEY.md §8 row f2. The GEMMs stay hipBLASLt
+// through torch: rag_dpo_amd/embedding_provider.py `_PackedEncoder`.)
+//
+// E1 k_enc_attention: self-attention of SHORT texts straight on the packed QKV projection. A batch of questions is ~20 tokens
+//    per text: the score matrix of a (text, head) is 20 x 20, the arithmetic is nothing, and what the padded-batch form costs is
+//    memory passes — scatter the packed projection into [batch][longest] slots, attention over the padding, a transposing copy,
+//    gather back (~0.7 GB per layer for BASELINE config 5's 1024 questions). Here: reads qkv [T][3H] once (keys and values of a
+//    text again from L1/L2 for each of its tokens), writes ctx [T][H] once. Roofline: HBM, T*4H*2 B per launch.
+//    Layout: 4 adjacent lanes own one (token, head) row, 16 of its 64 dimensions each: the row's q slice lives in registers, a key's
+//    score is 8 v_dot2_f32_f16 + a sum over the quad (DPP, no LDS), soft-max is the running-max form in fp32, the lane accumulates
+//    its 16 output dimensions. A quad's lanes share the text, so they run the same number of keys; quads of one wave may not.
+// E2 k_enc_add_ln: y = LayerNorm(a + b) * gamma + beta over rows of `hidden` halves, one wave per row, values kept in registers
+//    between the statistics and the output (torch: an add kernel, then LayerNorm: five passes over the row instead of three).
+//    The sum is rounded to fp16 before the statistics, as the two-kernel form does.
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "rdx_common.hpp"
+
+namespace rdx {
+
+constexpr int ENC_HEAD_DIM = 64;
+
+template <int CTRL>
+__device__ __forceinline__ float quad_swap_add(float v) {   // v + (the value of the lane CTRL's quad permutation names)
+    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(o);
+}
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// o + p * half(v), the half taken from the low / high 16 bits of a packed pair: ONE instruction (the compiler's choice for
+// `o += p * (float)v` is a v_cvt_f32_f16 per element plus packed fp32 FMAs: 24 instead of 16 instructions per key)
+__device__ __forceinline__ float fma_mix_lo(float p, uint32_t v, float o) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(p), "v"(v), "v"(o));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(float p, uint32_t v, float o) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(p), "v"(v), "v"(o));
+    return r;
+}
+
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dot16(const h8& q0, const h8& q1, const h8& k0, const h8& k1) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s = __builtin_amdgcn_fdot2(h2{q0[2 * e], q0[2 * e + 1]}, h2{k0[2 * e], k0[2 * e + 1]}, s, false);
+        s = __builtin_amdgcn_fdot2(h2{q1[2 * e], q1[2 * e + 1]}, h2{k1[2 * e], k1[2 * e + 1]}, s, false);
+    }
+    s = quad_swap_add<0xB1>(s);   // quad_perm [1,0,3,2]
+    return quad_swap_add<0x4E>(s);   // quad_perm [2,3,0,1]
+}
+
+// grid (ceil(T / 64), heads), 256 threads. Two keys per iteration: one running-max update and one rescale of the 16 accumulators
+// for both (an odd text's last iteration reads its last key twice and gives the copy the score -inf, i.e. weight 0).
+__global__ __launch_bounds__(256) void k_enc_attention(const _Float16* __restrict__ qkv, const int32_t* __restrict__ tok_first,
+                                                       const int32_t* __restrict__ tok_len, int64_t T, int heads, float scale,
+                                                       _Float16* __restrict__ ctx) {
+    const int g = threadIdx.x & 3;
+    const int64_t t = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int h = blockIdx.y;
+    const int64_t H = (int64_t)heads * ENC_HEAD_DIM, row = 3 * H;
+    const bool live = t < T;
+    const int64_t tt = live ? t : T - 1;
+    const int S = live ? tok_len[tt] : 0;
+    const int64_t first = tok_first[tt];
+    const int64_t col = (int64_t)h * ENC_HEAD_DIM + g * 16;
+    const h8* qp = reinterpret_cast<const h8*>(qkv + tt * row + col);
+    const h8 q0 = qp[0], q1 = qp[1];
+    const _Float16* kp = qkv + first * row + H + col;   // key 0 of this row's text; its value H halves further
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc = scale * LOG2E;                      // scores in units of log2: exp2 below
+    float m = -INFINITY, l = 0.f;
+    float o[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    for (int j = 0; j < S; j += 2, kp += 2 * row) {
+        const bool two = j + 1 < S;
+        const _Float16* kp2 = two ? kp + row : kp;
+        const h8 ka0 = reinterpret_cast<const h8*>(kp)[0], ka1 = reinterpret_cast<const h8*>(kp)[1];
+        const h8 kb0 = reinterpret_cast<const h8*>(kp2)[0], kb1 = reinterpret_cast<const h8*>(kp2)[1];
+        const u4 va0 = reinterpret_cast<const u4*>(kp + H)[0], va1 = reinterpret_cast<const u4*>(kp + H)[1];
+        const u4 vb0 = reinterpret_cast<const u4*>(kp2 + H)[0], vb1 = reinterpret_cast<const u4*>(kp2 + H)[1];
+        const float sa = dot16(q0, q1, ka0, ka1) * sc;
+        const float sb = two ? dot16(q0, q1, kb0, kb1) * sc : -INFINITY;
+        const float mn = fmaxf(m, fmaxf(sa, sb));
+        const float corr = __builtin_amdgcn_exp2f(m - mn);   // first iteration: exp2(-inf) = 0
+        const float pa = __builtin_amdgcn_exp2f(sa - mn), pb = __builtin_amdgcn_exp2f(sb - mn);
+        l = l * corr + pa + pb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] = fma_mix_lo(pb, vb0[e], fma_mix_lo(pa, va0[e], o[2 * e] * corr));
+            o[2 * e + 1] = fma_mix_hi(pb, vb0[e], fma_mix_hi(pa, va0[e], o[2 * e + 1] * corr));
+            o[8 + 2 * e] = fma_mix_lo(pb, vb1[e], fma_mix_lo(pa, va1[e], o[8 + 2 * e] * corr));
+            o[8 + 2 * e + 1] = fma_mix_hi(pb, vb1[e], fma_mix_hi(pa, va1[e], o[8 + 2 * e + 1] * corr));
+        }
+        m = mn;
+    }
+    if (live) {
+        const float inv = 1.f / l;   // S >= 1: l >= 1
+        h8 r0, r1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            r0[e] = (_Float16)(o[e] * inv);
+            r1[e] = (_Float16)(o[8 + e] * inv);
+        }
+        h8* op = reinterpret_cast<h8*>(ctx + t * H + col);
+        op[0] = r0;
+        op[1] = r1;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// NCH = hidden / 512 (each lane holds NCH chunks of 8 halves); grid ceil(rows / 4), 256 threads = 4 rows
+template <int NCH>
+__global__ __launch_bounds__(256) void k_enc_add_ln(const _Float16* __restrict__ a, const _Float16* __restrict__ b,
+                                                    const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta, float eps,
+                                                    int64_t rows, _Float16* __restrict__ out) {
+    constexpr int HID = NCH * 512;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float x[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int64_t off = r * HID + c * 512 + lane * 8;
+        const h8 va = *reinterpret_cast<const h8*>(a + off), vb = *reinterpret_cast<const h8*>(b + off);
+        const h8 vs = va + vb;   // fp16 sum, rounded like the stand-alone add kernel's
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x[c][e] = (float)vs[e];
+            sum += x[c][e];
+        }
+    }
+    const float mean = wave_sum(sum) * (1.f / HID);
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = x[c][e] - mean;
+            sq += d * d;
+        }
+    const float rstd = rsqrtf(wave_sum(sq) * (1.f / HID) + eps);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int cc = c * 512 + lane * 8;
+        const h8 gw = *reinterpret_cast<const h8*>(gamma + cc), bw = *reinterpret_cast<const h8*>(beta + cc);
+        h8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (_Float16)((x[c][e] - mean) * rstd * (float)gw[e] + (float)bw[e]);
+        *reinterpret_cast<h8*>(out + r * HID + cc) = y;
+    }
+}
+
+}  // namespace rdx

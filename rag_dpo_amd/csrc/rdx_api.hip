@@ -18,6 +18,7 @@
 
 #include <immintrin.h>
 
+#include "enc_kernels.hpp"
 #include "k_rows.hpp"
 #include "refine_kernel.hpp"
 #include "scan_kernel.hpp"
@@ -631,6 +632,43 @@ struct NormScratch {
 };
 // (never destroyed: a static destructor would call hipFree at process exit, possibly after the HIP runtime is gone)
 static NormScratch* const g_norm = new NormScratch[64];
+
+extern "C" int rdx_enc_attention_f16(int device, const void* qkv, const int32_t* tok_first, const int32_t* tok_len, int64_t n_tokens,
+                                     int heads, int head_dim, float scale, void* ctx, void* stream) {
+    if (n_tokens < 0 || heads < 1 || heads > 65535) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: bad shape");
+    if (head_dim != ENC_HEAD_DIM) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: head_dim must be 64");
+    if (n_tokens == 0) return RDX_OK;
+    if (!qkv || !tok_first || !tok_len || !ctx) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: null pointer");
+    if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: qkv and ctx must be 16-byte aligned");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_enc_attention, dim3((unsigned)((n_tokens + 63) / 64), (unsigned)heads), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)qkv, tok_first, tok_len, n_tokens, heads, scale, (_Float16*)ctx);
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
+extern "C" int rdx_enc_add_layernorm_f16(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps,
+                                         int64_t rows, int hidden, void* out, void* stream) {
+    if (rows < 0 || hidden < 512 || hidden > 2048 || hidden % 512) return fail(RDX_ERR_INVALID, "rdx_enc_add_layernorm_f16: hidden must be 512, 1024, 1536 or 2048");
+    if (rows == 0) return RDX_OK;
+    if (!a || !b || !gamma || !beta || !out) return fail(RDX_ERR_INVALID, "rdx_enc_add_layernorm_f16: null pointer");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15)
+        return fail(RDX_ERR_INVALID, "rdx_enc_add_layernorm_f16: pointers must be 16-byte aligned");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_add_layernorm_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16 *pa = (const _Float16*)a, *pb = (const _Float16*)b, *pg = (const _Float16*)gamma, *pbt = (const _Float16*)beta;
+    switch (hidden / 512) {
+        case 1: hipLaunchKernelGGL(k_enc_add_ln<1>, grid, block, 0, st, pa, pb, pg, pbt, eps, rows, (_Float16*)out); break;
+        case 2: hipLaunchKernelGGL(k_enc_add_ln<2>, grid, block, 0, st, pa, pb, pg, pbt, eps, rows, (_Float16*)out); break;
+        case 3: hipLaunchKernelGGL(k_enc_add_ln<3>, grid, block, 0, st, pa, pb, pg, pbt, eps, rows, (_Float16*)out); break;
+        default: hipLaunchKernelGGL(k_enc_add_ln<4>, grid, block, 0, st, pa, pb, pg, pbt, eps, rows, (_Float16*)out); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
 
 extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space, void* stream) {
     if (n < 0 || (n > 0 && (!in || !out))) return fail(RDX_ERR_INVALID, "rdx_l2_normalize: bad argument");

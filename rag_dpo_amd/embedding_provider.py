@@ -87,9 +87,10 @@ class _PackedEncoder:
     (index_select). The three projections are ONE GEMM on concatenated weights. About half the launches of the module-by-module
     forward (the encode of a batch is launch-bound on a busy host) and 28 % fewer GEMM rows for that batch. Same arithmetic per
     token as `XLMRobertaModel.forward` (post-LayerNorm blocks, erf GELU, position ids = padding_idx + 1 + index in the text,
-    attention over the text's own tokens only): tests/test_embedding_provider.py compares the two."""
+    attention over the text's own tokens only): tests/test_embedding_provider.py compares the two. With `fused` (fp16 on a GPU)
+    the attention and the add + LayerNorm pairs are librdx kernels working on the packed layout directly: nothing is ever padded."""
 
-    def __init__(self, model):
+    def __init__(self, model, fused: bool = False):
         e = model.embeddings
         self.word, self.pos, self.typ, self.ln, self.pad = e.word_embeddings, e.position_embeddings, e.token_type_embeddings, e.LayerNorm, int(e.padding_idx)
         cfg = model.config
@@ -104,6 +105,39 @@ class _PackedEncoder:
             bqkv = torch.cat([a.self.query.bias, a.self.key.bias, a.self.value.bias], 0).contiguous()
             self.layers.append((wqkv, bqkv, a.output.dense, a.output.LayerNorm, L.intermediate.dense, L.output.dense, L.output.LayerNorm))
         self._pad_buf: dict = {}
+        # librdx's two encoder kernels (include/rdx.h: rdx_enc_attention_f16, rdx_enc_add_layernorm_f16) take the place of the
+        # scatter -> padded attention -> transposing copy -> gather chain and of the add + LayerNorm pairs: fp16 on a GPU, 64-wide
+        # heads, hidden a multiple of 512 up to 2048, texts up to FUSED_MAX_TOKENS tokens (the attention kernel is written for
+        # questions: its work per token grows with the text). Anything else runs the torch operations below.
+        self._lib = None
+        self.fused = False
+        p0 = self.layers[0][0]
+        if fused and p0.is_cuda and p0.dtype == torch.float16 and self.hidden // self.heads == 64 and self.hidden % 512 == 0 and self.hidden <= 2048:
+            from . import _lib
+            self._lib = _lib.load()          # raises RdxUnavailable: a GPU provider asked for its kernels and the library is missing
+            self._last_error = _lib.last_error
+            self.fused = True
+
+    FUSED_MAX_TOKENS = 64
+
+    def _add_ln(self, a: torch.Tensor, b: torch.Tensor, ln) -> torch.Tensor:
+        out = torch.empty_like(a)
+        rc = self._lib.rdx_enc_add_layernorm_f16(a.device.index or 0, a.data_ptr(), b.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                                 float(ln.eps), a.shape[0], a.shape[1], out.data_ptr(),
+                                                 torch.cuda.current_stream(a.device).cuda_stream)
+        if rc:
+            raise RuntimeError("rdx_enc_add_layernorm_f16: " + self._last_error())
+        return out
+
+    def _attention(self, qkv: torch.Tensor, tok_first: torch.Tensor, tok_len: torch.Tensor) -> torch.Tensor:
+        T = qkv.shape[0]
+        ctx = torch.empty((T, self.hidden), dtype=qkv.dtype, device=qkv.device)
+        rc = self._lib.rdx_enc_attention_f16(qkv.device.index or 0, qkv.data_ptr(), tok_first.data_ptr(), tok_len.data_ptr(), T, self.heads,
+                                             self.hidden // self.heads, (self.hidden // self.heads) ** -0.5, ctx.data_ptr(),
+                                             torch.cuda.current_stream(qkv.device).cuda_stream)
+        if rc:
+            raise RuntimeError("rdx_enc_attention_f16: " + self._last_error())
+        return ctx
 
     @torch.no_grad()
     def cls(self, ids: torch.Tensor, lens: np.ndarray, to_dev) -> torch.Tensor:
@@ -116,29 +150,43 @@ class _PackedEncoder:
         first = np.cumsum(lens) - lens                                   # packed index of every text's first token (CLS)
         row = np.repeat(np.arange(B, dtype=np.int64), lens)
         col = np.arange(T, dtype=np.int64) - np.repeat(first, lens)
-        flat = row * S + col                                             # slot of packed token t in the padded [B*S] layout
         ids_np = ids.numpy()
         tok = to_dev("pk_tok", torch.from_numpy(np.ascontiguousarray(ids_np[row, col])))
         pos = to_dev("pk_pos", torch.from_numpy(col + (self.pad + 1)))
-        flat_d = to_dev("pk_flat", torch.from_numpy(flat))
         first_d = to_dev("pk_first", torch.from_numpy(first))
-        kmask = to_dev("pk_mask", torch.from_numpy(np.arange(S)[None, :] < lens[:, None])).view(B, 1, 1, S)   # keys of the text itself
         x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
         H, nh = self.hidden, self.heads
-        key = (B, S, x.dtype, x.device)
-        qkv_pad = self._pad_buf.get(key)
-        if qkv_pad is None:
-            if len(self._pad_buf) > 8:
-                self._pad_buf.clear()
-            qkv_pad = self._pad_buf[key] = torch.zeros((B * S, 3 * H), dtype=x.dtype, device=x.device)   # (stale padding slots are masked keys / dropped queries)
-        for wqkv, bqkv, dense_o, ln1, inter, out, ln2 in self.layers:
-            qkv_pad.index_copy_(0, flat_d, F.linear(x, wqkv, bqkv))
-            q, k, v = qkv_pad.view(B, S, 3, nh, H // nh).permute(2, 0, 3, 1, 4)                                   # [B][heads][S][head_dim] views
-            ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=kmask)
-            ctx = ctx.transpose(1, 2).reshape(B * S, H).index_select(0, flat_d)                                   # back to [T][H]
-            x = ln1(dense_o(ctx) + x)
-            x = ln2(out(F.gelu(inter(x))) + x)
-        return x.index_select(0, first_d).to(torch.float32)
+        fused = self.fused and int(lens.max()) <= self.FUSED_MAX_TOKENS
+        if fused:
+            tok_first = to_dev("pk_tfirst", torch.from_numpy(np.repeat(first, lens).astype(np.int32)))
+            tok_len = to_dev("pk_tlen", torch.from_numpy(np.repeat(lens, lens).astype(np.int32)))
+        else:
+            flat_d = to_dev("pk_flat", torch.from_numpy(row * S + col))                                          # slot of packed token t in the padded [B*S] layout
+            kmask = to_dev("pk_mask", torch.from_numpy(np.arange(S)[None, :] < lens[:, None])).view(B, 1, 1, S)   # keys of the text itself
+            key = (B, S, x.dtype, x.device)
+            qkv_pad = self._pad_buf.get(key)
+            if qkv_pad is None:
+                if len(self._pad_buf) > 8:
+                    self._pad_buf.clear()
+                qkv_pad = self._pad_buf[key] = torch.zeros((B * S, 3 * H), dtype=x.dtype, device=x.device)   # (stale padding slots are masked keys / dropped queries)
+        last = len(self.layers) - 1
+        for li, (wqkv, bqkv, dense_o, ln1, inter, out, ln2) in enumerate(self.layers):
+            if fused:
+                ctx = self._attention(F.linear(x, wqkv, bqkv), tok_first, tok_len)                                # [T][H], no padding anywhere
+            else:
+                qkv_pad.index_copy_(0, flat_d, F.linear(x, wqkv, bqkv))
+                q, k, v = qkv_pad.view(B, S, 3, nh, H // nh).permute(2, 0, 3, 1, 4)                               # [B][heads][S][head_dim] views
+                ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=kmask)
+                ctx = ctx.transpose(1, 2).reshape(B * S, H).index_select(0, flat_d)                               # back to [T][H]
+            if li == last:                                   # everything behind the last attention is row-wise: only the CLS rows are needed
+                ctx, x = ctx.index_select(0, first_d), x.index_select(0, first_d)
+            if fused:
+                x = self._add_ln(dense_o(ctx), x, ln1)
+                x = self._add_ln(out(F.gelu(inter(x))), x, ln2)
+            else:
+                x = ln1(dense_o(ctx) + x)
+                x = ln2(out(F.gelu(inter(x))) + x)
+        return x.to(torch.float32)
 
 
 def _resolve_local_dir(model_name: str, cache_dir: Optional[str]) -> Optional[str]:
@@ -196,6 +244,9 @@ class EmbeddingProvider:
             if spec.startswith("tiny"):     # tests: same architecture, toy size
                 cfg.update(hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, vocab_size=1000,
                            max_position_embeddings=514)
+            elif spec.startswith("mid"):    # tests of the fused kernels: 64-wide heads, hidden a multiple of 512
+                cfg.update(hidden_size=512, num_hidden_layers=3, num_attention_heads=8, intermediate_size=1024, vocab_size=1000,
+                           max_position_embeddings=514)
             torch.manual_seed(0)
             model = XLMRobertaModel(XLMRobertaConfig(**cfg), add_pooling_layer=False)
             self._tokenizer = _HashTokenizer(cfg["vocab_size"], max_len=min(512, cfg["max_position_embeddings"] - 2))
@@ -215,8 +266,9 @@ class EmbeddingProvider:
         self._packed = None
         if self.packed_forward:
             try:
-                self._packed = _PackedEncoder(self._model)
-            except Exception as e:                                            # noqa: BLE001  (another architecture: the module forward stays)
+                fused = self.fused_kernels if self.fused_kernels is not None else (str(self.device).startswith("cuda") and self.dtype == torch.float16)
+                self._packed = _PackedEncoder(self._model, fused=bool(fused))
+            except ValueError as e:                                           # another architecture: the module forward stays
                 logger.info(f"packed forward not available for this model ({e}); using the module forward")
         logger.info(f"{self.model_name} loaded in {time.time() - t0:.1f}s (dims={self._dims})")
         return self
@@ -233,6 +285,7 @@ class EmbeddingProvider:
     # 1024 query texts to one call) one batch means one width: 8-24-word questions padded to the longest are ~30 % padding
     # tokens. A batch is therefore cut, after tokenising, into at most `max_buckets` buckets of consecutive (token-count-sorted)
     # rows, each forwarded at its own width; the cuts (multiples of 64 rows) minimise padded tokens + a per-forward charge.
+    fused_kernels: Optional[bool] = None   # None: librdx's encoder kernels whenever the provider runs fp16 on a GPU (the library must load); False: torch operations only
     packed_forward = True              # _PackedEncoder: token-wise layers over the real tokens only (padding only around the attention)
     max_buckets = 4
     bucket_granule = 64

@@ -205,3 +205,116 @@ def test_packed_forward_equals_the_module_forward():
     assert len(fast.last_encode_stats["buckets"]) == 1            # padding costs the attention only: one forward
     fast.batch_size = 50                                          # several batches
     assert torch.allclose(fast._encode_raw(texts), a, atol=2e-5, rtol=1e-5)
+
+
+def _attention_reference(qkv, lens, heads):
+    """softmax(q k^T / sqrt(d)) v per text and head in fp32, on the packed [T][3H] projection"""
+    import torch
+    T, H3 = qkv.shape
+    H = H3 // 3
+    d = H // heads
+    out = torch.empty((T, H), dtype=torch.float32)
+    t0 = 0
+    x = qkv.float()
+    for n in lens:
+        blk = x[t0:t0 + n]
+        q, k, v = (blk[:, i * H:(i + 1) * H].view(n, heads, d).transpose(0, 1) for i in range(3))   # [heads][n][d]
+        p = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, dim=-1)
+        out[t0:t0 + n] = (p @ v).transpose(0, 1).reshape(n, H)
+        t0 += n
+    return out
+
+
+@pytest.mark.gpu
+def test_encoder_attention_kernel_vs_fp32_reference():
+    """rdx_enc_attention_f16 (self-attention of short texts on the packed QKV projection) against a plain fp32 torch reference of the
+    same op: ragged lengths 1..64, a token count that is no multiple of the block's 64 rows, large score magnitudes.
+    Tolerance: the output is fp16 (half an ulp of values up to ~4: 2e-3) on fp32 arithmetic over the same fp16 inputs."""
+    import torch
+    from rag_dpo_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    for heads, lens in ((16, [1, 64, 7, 20, 33, 2, 19, 21, 5]), (8, list(rng.integers(1, 30, size=200))), (2, [3])):
+        H = heads * 64
+        T = int(sum(lens))
+        g = torch.Generator().manual_seed(T)
+        qkv = (torch.randn((T, 3 * H), generator=g) * 1.5).half()
+        first = np.cumsum(lens) - np.asarray(lens)
+        tf = torch.from_numpy(np.repeat(first, lens).astype(np.int32)).cuda()
+        tl = torch.from_numpy(np.repeat(lens, lens).astype(np.int32)).cuda()
+        qd = qkv.cuda()
+        ctx = torch.full((T, H), float("nan"), dtype=torch.float16, device="cuda")
+        rc = L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), T, heads, 64, 0.125, ctx.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        want = _attention_reference(qkv, [int(n) for n in lens], heads)
+        got = ctx.float().cpu()
+        assert torch.isfinite(got).all()
+        assert float((got - want).abs().max()) <= 3e-3, float((got - want).abs().max())
+    # argument checks: wrong head width, misaligned pointer
+    assert L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), T, heads, 32, 0.125, ctx.data_ptr(), 0) != 0
+    assert L.rdx_enc_attention_f16(0, qd.data_ptr() + 2, tf.data_ptr(), tl.data_ptr(), T, heads, 64, 0.125, ctx.data_ptr(), 0) != 0
+    assert L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), 0, heads, 64, 0.125, ctx.data_ptr(), 0) == 0
+
+
+@pytest.mark.gpu
+def test_encoder_add_layernorm_kernel_vs_torch():
+    """rdx_enc_add_layernorm_f16 against torch's fp16 add followed by LayerNorm (fp32 statistics) and against the fp32 reference of
+    LayerNorm(half(a + b)): every supported width, a row count that is no multiple of 4. Tolerance: one fp16 ulp of the output."""
+    import torch
+    from rag_dpo_amd import _lib
+    L = _lib.load()
+    for hidden in (512, 1024, 1536, 2048):
+        g = torch.Generator().manual_seed(hidden)
+        rows = 1001
+        a = (torch.randn((rows, hidden), generator=g) * 2).half().cuda()
+        b = (torch.randn((rows, hidden), generator=g) + 0.5).half().cuda()
+        ln = torch.nn.LayerNorm(hidden, eps=1e-5)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(hidden, generator=g) * 0.3 + 1)
+            ln.bias.copy_(torch.randn(hidden, generator=g) * 0.2)
+        ref32 = ln((a + b).float().cpu())                        # fp32 LayerNorm of the fp16-rounded sum
+        ln = ln.half().cuda()
+        out = torch.empty_like(a)
+        rc = L.rdx_enc_add_layernorm_f16(0, a.data_ptr(), b.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), 1e-5, rows, hidden,
+                                         out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _lib.last_error()
+        with torch.no_grad():
+            want = ln(a + b)
+        torch.cuda.synchronize()
+        ulp = 2.0 ** -10 * torch.clamp(want.float().abs(), min=1.0)
+        assert bool(((out.float() - want.float()).abs() <= ulp).all()), float((out.float() - want.float()).abs().max())
+        ref16 = torch.nn.functional.layer_norm((a + b).float().cpu(), (hidden,), ln.weight.float().cpu(), ln.bias.float().cpu(), 1e-5)
+        assert float((out.float().cpu() - ref16.detach()).abs().max()) <= 4e-3
+        del ref32
+    assert L.rdx_enc_add_layernorm_f16(0, a.data_ptr(), b.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), 1e-5, rows, 768,
+                                       out.data_ptr(), 0) != 0
+
+
+@pytest.mark.gpu
+def test_fused_encoder_kernels_equal_the_torch_operations():
+    """the whole packed forward with librdx's attention and add + LayerNorm kernels against the same forward on torch operations
+    (and against the module forward): same weights (seeded), fp16 on the GPU, 64-wide heads; texts of 1..60 tokens take the kernels,
+    a batch with one long text takes the torch path — both must agree with the reference to fp16 accuracy"""
+    import torch
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    rng = np.random.default_rng(4)
+    words = [f"w{i}" for i in range(300)]
+    short = [" ".join(rng.choice(words, size=int(n))) for n in rng.integers(1, 40, size=300)] + ["w1"]
+    long_ = short[:20] + [" ".join(rng.choice(words, size=150))]
+
+    def make(fused, packed=True):
+        p = EmbeddingProvider(model_name="random-init:mid", device="cuda:0", dtype=torch.float16, batch_size=512)
+        p.fused_kernels, p.packed_forward = fused, packed
+        return p.load()
+
+    fast, plain, module = make(None), make(False), make(False, packed=False)
+    assert fast._packed.fused and not plain._packed.fused and module._packed is None
+    for texts in (short, long_):
+        a, b, c = (torch.nn.functional.normalize(p.embed_device(texts).float(), dim=1) for p in (fast, plain, module))   # (raw CLS rows: the index normalises)
+        torch.cuda.synchronize()
+        for other in (b, c):
+            cos = (a * other).sum(1)
+            assert float((1 - cos).abs().max()) <= 2e-5, float((1 - cos).abs().max())
+            assert float((a - other).abs().max()) <= 2e-3
