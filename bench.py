@@ -314,6 +314,7 @@ def main():
     scan_ms, tot_ms, stats = 0.0, 0.0, None
     exact_ms = 0.0
     serial = None
+    host_ms = [0.0, 0.0, 0.0]
     if encode and not args.no_overlap:
         # C5 step = encode B texts + search, software-pipelined on ONE stream: the search of batch i is enqueued
         # (search_begin), the encode of batch i+1 — tokenising on the host, then the forward's launches — is issued behind it
@@ -342,12 +343,19 @@ def main():
             return q_
 
         q_next = encode_now()
+        host_ms = [0.0, 0.0, 0.0]          # where the HOST spends a pipelined step: search_begin, the next encode's enqueue, search_end (its wait)
         for i in range(args.steps):
             q_cur = q_next
+            h0 = time.perf_counter()
             searcher.search_begin(q_cur, k)
+            h1 = time.perf_counter()
             if i + 1 < args.steps:
                 q_next = encode_now()
+            h2 = time.perf_counter()
             searcher.search_end()
+            h3 = time.perf_counter()
+            for j, d in enumerate((h1 - h0, h2 - h1, h3 - h2)):
+                host_ms[j] += d * 1e3
             st = shard.index.last_stats()
             scan_ms += st["ms_scan_main"]
             exact_ms += st["ms_exact"]
@@ -603,7 +611,9 @@ def main():
             "merged_equals_single_index": merged_ok, "rccl": rccl_info, "distributed_check": dist_check, "step_breakdown": step_breakdown,
             "encode": ({"model": "XLM-R-large (BGE-M3 architecture), random-init fp16, hashing tokenizer", "texts_per_step": B,
                         "avg_ms": round(sum(a.elapsed_time(b) for a, b in enc_ev) / max(1, len(enc_ev)), 3),
-                        "pipelined_with_search": bool(serial is not None), "serial_leg": serial, "length_buckets": enc_stats,
+                        "pipelined_with_search": bool(serial is not None), "serial_leg": serial,
+                        "host_ms_per_step": ({"search_begin": round(host_ms[0] / args.steps, 3), "next_encode_enqueue": round(host_ms[1] / args.steps, 3),
+                                              "search_end_wait": round(host_ms[2] / args.steps, 3)} if serial is not None else None), "length_buckets": enc_stats,
                         "note": "encoder value parity unpinned (no BGE-M3 weights offline); PyTorch-ROCm plumbing, not a librdx kernel"} if encode else None),
             "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4),"exact_fallback_queries": stats["exact_queries"],
                            "emitted_per_query": round(stats["emitted"] / max(1, B), 1),

@@ -8,8 +8,9 @@
 //    gather back (~0.7 GB per layer for BASELINE config 5's 1024 questions). Here: reads qkv [T][3H] once (keys and values of a
 //    text again from L1/L2 for each of its tokens), writes ctx [T][H] once. Roofline: HBM, T*4H*2 B per launch.
 //    Layout: 4 adjacent lanes own one (token, head) row, 16 of its 64 dimensions each: the row's q slice lives in registers, a key's
-//    score is 8 v_dot2_f32_f16 + a sum over the quad (DPP, no LDS), soft-max is the running-max form in fp32, the lane accumulates
-//    its 16 output dimensions. A quad's lanes share the text, so they run the same number of keys; quads of one wave may not.
+//    score is 8 v_dot2_f32_f16 + a sum over the quad (DPP), soft-max is the running-max form in fp32, the lane accumulates its 16
+//    output dimensions (v_fma_mix_f32 straight from the fp16 values). The keys and values of a workgroup's texts are staged in LDS.
+//    A quad's lanes share the text, so they run the same number of keys; quads of one wave may not.
 // E2 k_enc_add_ln: y = LayerNorm(a + b) * gamma + beta over rows of `hidden` halves, one wave per row, values kept in registers
 //    between the statistics and the output (torch: an add kernel, then LayerNorm: five passes over the row instead of three).
 //    The sum is rounded to fp16 before the statistics, as the two-kernel form does.
@@ -57,36 +58,21 @@ __device__ __forceinline__ float dot16(const h8& q0, const h8& q1, const h8& k0,
     return quad_swap_add<0x4E>(s);   // quad_perm [2,3,0,1]
 }
 
-// grid (ceil(T / 64), heads), 256 threads. Two keys per iteration: one running-max update and one rescale of the 16 accumulators
-// for both (an odd text's last iteration reads its last key twice and gives the copy the score -inf, i.e. weight 0).
-__global__ __launch_bounds__(256) void k_enc_attention(const _Float16* __restrict__ qkv, const int32_t* __restrict__ tok_first,
-                                                       const int32_t* __restrict__ tok_len, int64_t T, int heads, float scale,
-                                                       _Float16* __restrict__ ctx) {
-    const int g = threadIdx.x & 3;
-    const int64_t t = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
-    const int h = blockIdx.y;
-    const int64_t H = (int64_t)heads * ENC_HEAD_DIM, row = 3 * H;
-    const bool live = t < T;
-    const int64_t tt = live ? t : T - 1;
-    const int S = live ? tok_len[tt] : 0;
-    const int64_t first = tok_first[tt];
-    const int64_t col = (int64_t)h * ENC_HEAD_DIM + g * 16;
-    const h8* qp = reinterpret_cast<const h8*>(qkv + tt * row + col);
-    const h8 q0 = qp[0], q1 = qp[1];
-    const _Float16* kp = qkv + first * row + H + col;   // key 0 of this row's text; its value H halves further
-    constexpr float LOG2E = 1.4426950408889634f;
-    const float sc = scale * LOG2E;                      // scores in units of log2: exp2 below
-    float m = -INFINITY, l = 0.f;
-    float o[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] = 0.f;
-    for (int j = 0; j < S; j += 2, kp += 2 * row) {
+constexpr int ENC_KEY_WINDOW = 192;   // keys (and values) of one head a workgroup stages in LDS: 64 rows of texts up to 64 tokens need <= 190
+
+// One row's attention over the S keys at `kv` (key j: 16 of its 64 dims at kv + j * STRIDE halves, its value VOFF halves further).
+// Two keys per iteration: one running-max update and one rescale of the 16 accumulators for both (an odd text's last iteration
+// reads its last key twice and gives the copy the score -inf, i.e. weight 0).
+template <class P>
+__device__ __forceinline__ void attend_row(P kv, int64_t stride, int64_t voff, int S, const h8& q0, const h8& q1, float sc, float (&o)[16], float& l) {
+    float m = -INFINITY;
+    for (int j = 0; j < S; j += 2, kv += 2 * stride) {
         const bool two = j + 1 < S;
-        const _Float16* kp2 = two ? kp + row : kp;
-        const h8 ka0 = reinterpret_cast<const h8*>(kp)[0], ka1 = reinterpret_cast<const h8*>(kp)[1];
-        const h8 kb0 = reinterpret_cast<const h8*>(kp2)[0], kb1 = reinterpret_cast<const h8*>(kp2)[1];
-        const u4 va0 = reinterpret_cast<const u4*>(kp + H)[0], va1 = reinterpret_cast<const u4*>(kp + H)[1];
-        const u4 vb0 = reinterpret_cast<const u4*>(kp2 + H)[0], vb1 = reinterpret_cast<const u4*>(kp2 + H)[1];
+        P kv2 = two ? kv + stride : kv;
+        const h8 ka0 = reinterpret_cast<const h8*>(kv)[0], ka1 = reinterpret_cast<const h8*>(kv)[1];
+        const h8 kb0 = reinterpret_cast<const h8*>(kv2)[0], kb1 = reinterpret_cast<const h8*>(kv2)[1];
+        const u4 va0 = reinterpret_cast<const u4*>(kv + voff)[0], va1 = reinterpret_cast<const u4*>(kv + voff)[1];
+        const u4 vb0 = reinterpret_cast<const u4*>(kv2 + voff)[0], vb1 = reinterpret_cast<const u4*>(kv2 + voff)[1];
         const float sa = dot16(q0, q1, ka0, ka1) * sc;
         const float sb = two ? dot16(q0, q1, kb0, kb1) * sc : -INFINITY;
         const float mn = fmaxf(m, fmaxf(sa, sb));
@@ -102,6 +88,49 @@ __global__ __launch_bounds__(256) void k_enc_attention(const _Float16* __restric
         }
         m = mn;
     }
+}
+
+// grid (ceil(T / 64), heads), 256 threads = 64 consecutive tokens of one head. The texts those tokens belong to are a contiguous
+// range of tokens: their keys and values of this head (256 B per token) are staged in LDS once per workgroup — every key is
+// wanted by all tokens of its text, and 16-byte loads of the same few lines by every lane are what the CU's vector L1 is slowest
+// at (64 B/clk against the LDS's 256 B/clk with broadcast). Rows whose text does not lie inside the window (texts longer than
+// the kernel is meant for) read global memory instead: same arithmetic.
+__global__ __launch_bounds__(256) void k_enc_attention(const _Float16* __restrict__ qkv, const int32_t* __restrict__ tok_first,
+                                                       const int32_t* __restrict__ tok_len, int64_t T, int heads, float scale,
+                                                       _Float16* __restrict__ ctx) {
+    __shared__ __attribute__((aligned(16))) _Float16 kv_s[ENC_KEY_WINDOW * 128];   // [key][K 64 | V 64]
+    const int g = threadIdx.x & 3;
+    const int64_t t0 = (int64_t)blockIdx.x * 64;
+    const int64_t t = t0 + (threadIdx.x >> 2);
+    const int h = blockIdx.y;
+    const int64_t H = (int64_t)heads * ENC_HEAD_DIM, row = 3 * H;
+    const bool live = t < T;
+    const int64_t tt = live ? t : T - 1;
+    const int S = live ? tok_len[tt] : 0;
+    const int64_t first = tok_first[tt];
+    const int64_t col = (int64_t)h * ENC_HEAD_DIM + g * 16;
+    // the window: from the first token of the text of this workgroup's first row
+    const int64_t tl = t0 + 63 < T ? t0 + 63 : T - 1;
+    const int64_t kfirst = tok_first[t0];
+    const int64_t kend = (int64_t)tok_first[tl] + tok_len[tl];
+    const int nk = (int)(kend - kfirst < ENC_KEY_WINDOW ? kend - kfirst : ENC_KEY_WINDOW);
+    for (int c = threadIdx.x; c < nk * 16; c += 256) {
+        const int tok = c >> 4, part = c & 15;   // 16-byte pieces 0..7: the key's 64 dims, 8..15: the value's
+        const _Float16* src = qkv + (kfirst + tok) * row + H * (1 + (part >> 3)) + h * ENC_HEAD_DIM + (part & 7) * 8;
+        *reinterpret_cast<h8*>(kv_s + tok * 128 + part * 8) = *reinterpret_cast<const h8*>(src);
+    }
+    const h8* qp = reinterpret_cast<const h8*>(qkv + tt * row + col);
+    const h8 q0 = qp[0], q1 = qp[1];
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float sc = scale * LOG2E;                      // scores in units of log2: exp2 in attend_row
+    float l = 0.f;
+    float o[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    __syncthreads();
+    const int64_t rel = first - kfirst;                  // >= 0: texts are stored in order
+    if (rel + S <= nk) attend_row(kv_s + rel * 128 + g * 16, (int64_t)128, (int64_t)64, S, q0, q1, sc, o, l);
+    else attend_row(qkv + first * row + H + col, row, H, S, q0, q1, sc, o, l);
     if (live) {
         const float inv = 1.f / l;   // S >= 1: l >= 1
         h8 r0, r1;

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -838,6 +839,10 @@ static int ensure_pin_out(rdx_index* h, size_t bytes) {
 // The search numbered `seq` has completed: its k_finish published the mailbox. Spin on the pinned word for a while
 // (short searches: the store arrives a couple of us after the kernel, no interrupt, no D2H copy), then fall back to
 // hipStreamSynchronize (long searches; it also surfaces a faulted kernel).
+// Waits for THIS search's mailbox word, never for the stream: an asynchronous caller may have enqueued other work behind the
+// search (BASELINE config 5: the next batch's query encode, 15 ms of kernels), and a stream synchronise would wait for that too.
+// Hot spin for 0.4 ms (a small search ends inside it), then poll between 20 us sleeps; the stream is only QUERIED, every 50 ms,
+// to turn a failed or vanished search into an error instead of an endless wait.
 static int wait_search(rdx_index* h, hipStream_t st, unsigned long long seq) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
@@ -845,10 +850,20 @@ static int wait_search(rdx_index* h, hipStream_t st, unsigned long long seq) {
         _mm_pause();
         if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
     }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (__atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) != seq)
-        return fail(RDX_ERR_HIP, "internal: the search completed without publishing its mailbox");
-    return RDX_OK;
+    auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
+    for (;;) {
+        if (__atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) == seq) return RDX_OK;
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (std::chrono::steady_clock::now() >= next_query) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipSuccess) {   // everything enqueued has run: the word must be there
+                if (__atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) == seq) return RDX_OK;
+                return fail(RDX_ERR_HIP, "internal: the search completed without publishing its mailbox");
+            }
+            if (e != hipErrorNotReady) return fail(RDX_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+            next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
+        }
+    }
 }
 
 // depth 0 = the caller's batch; depth 1 = the second-chance batch of queries whose candidate segments overflowed

@@ -296,10 +296,13 @@ class EmbeddingProvider:
     last_encode_stats: Optional[dict] = None
 
     def _h2d(self, name: str, t: torch.Tensor) -> torch.Tensor:
-        """small host tensor -> device WITHOUT blocking the host: through a pinned staging buffer (one per name and shape, guarded
-        by an event: it is not overwritten before the copy that read it last has run). A pageable `.to(device)` is a synchronous copy:
-        it parks the host until everything enqueued on the stream so far — the previous batch's search — has finished, and the ~600
-        launches of the forward then start late (BASELINE config 5's pipeline: the encode of batch i+1 is issued behind search i)."""
+        """small host tensor -> device WITHOUT blocking the host: through pinned staging buffers (a ring of PIN_RING per name and
+        shape, each guarded by an event: it is not overwritten before the copy that read it last has run). A pageable
+        `.to(device)` is a synchronous copy: it parks the host until everything enqueued on the stream so far — the previous batch's
+        search — has finished, and the launches of the forward then start late (BASELINE config 5's pipeline: the encode of batch
+        i+1 is issued behind search i, while the GPU may still be running the encode of batch i). A ring, not one buffer: the copy a
+        buffer waits for belongs to the encode before the previous one — with a single buffer the "rows" copy at the END of encode i
+        made the host wait for the whole of encode i before it could issue encode i+1 (measured: 12 of 17 ms of host time per step)."""
         if not str(self.device).startswith("cuda"):
             return t.to(self.device)
         key = (name, tuple(t.shape), t.dtype)
@@ -307,16 +310,20 @@ class EmbeddingProvider:
         if ent is None:
             if len(self._pinned) > 64:
                 self._pinned.clear()
-            ent = self._pinned[key] = [torch.empty(t.shape, dtype=t.dtype).pin_memory(), None]
-        buf, ev = ent
+            ent = self._pinned[key] = [0, [[torch.empty(t.shape, dtype=t.dtype).pin_memory(), None] for _ in range(self.PIN_RING)]]
+        slot = ent[1][ent[0]]
+        ent[0] = (ent[0] + 1) % self.PIN_RING
+        buf, ev = slot
         if ev is not None:
             ev.synchronize()
         buf.copy_(t)
         d = buf.to(self.device, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        ent[1] = ev
+        slot[1] = ev
         return d
+
+    PIN_RING = 3
 
     def _forward_cls(self, feed: dict) -> torch.Tensor:
         """fp32 CLS rows of one padded bucket. (Round 3 also built a HIP-graph replay of this forward — ~700 launches that a busy host

@@ -12,5 +12,5 @@ import json
 for rnd in (1,2):
     for v in ("fused","packed","module"):
         d=json.load(open("$O/c5_%s_%d.json"%(v,rnd))); e=d["encode"]
-        print(rnd, v, d["value"], d["ms_per_step"], "enc", e["avg_ms"], "serial", e["serial_leg"], e["length_buckets"]["buckets"])
+        print(rnd, v, d["value"], d["ms_per_step"], "enc", e["avg_ms"], "serial", e["serial_leg"], e["length_buckets"]["buckets"], e.get("host_ms_per_step"))
 PY
