@@ -614,7 +614,8 @@ def main():
                         "pipelined_with_search": bool(serial is not None), "serial_leg": serial,
                         "host_ms_per_step": ({"search_begin": round(host_ms[0] / args.steps, 3), "next_encode_enqueue": round(host_ms[1] / args.steps, 3),
                                               "search_end_wait": round(host_ms[2] / args.steps, 3)} if serial is not None else None), "length_buckets": enc_stats,
-                        "note": "encoder value parity unpinned (no BGE-M3 weights offline); PyTorch-ROCm plumbing, not a librdx kernel"} if encode else None),
+                        "note": "encoder value parity unpinned (no BGE-M3 weights offline); the GEMMs and GELU are PyTorch-ROCm plumbing, the attention and the add + LayerNorm pairs "
+                                "are librdx kernels when length_buckets.forward says so (each checked against a torch fp32 reference of the same op in tests/)"} if encode else None),
             "path_stats": {"avg_search_ms_events": round(tot_ms / args.steps, 4),"exact_fallback_queries": stats["exact_queries"],
                            "emitted_per_query": round(stats["emitted"] / max(1, B), 1),
                            "rescored_per_query": round(stats["rescored"] / max(1, B), 2), "sample_rows": stats["sample_rows"],

@@ -178,7 +178,8 @@ int rdx_search_masked(rdx_index* h, const float* queries, int64_t nq, int k, con
 /* The search in two halves, for callers that enqueue consumers of the results on the same stream (the multi-GPU path: the
  * RCCL all-gather of the partial top-k and the merge, reference has no counterpart). rdx_search_async enqueues the whole
  * search (device pointers only, nq <= 4096; mask may be NULL) and returns without waiting; rdx_search_wait blocks until that
- * search has completed and runs its host half: when some queries' candidate segments overflowed (rare: clustered corpora) it
+ * search — not the stream: work enqueued behind it, e.g. the next batch's query encode, is not waited for — has completed and
+ * runs its host half: when some queries' candidate segments overflowed (rare: clustered corpora) it
  * re-runs them through the fallback passes, synchronises the stream and reports *redone = 1 — results written by the first
  * pass were incomplete for those queries, so whatever consumed them on the stream must be re-enqueued. Any other call on
  * the index completes a pending search first. rdx_search == rdx_search_async + rdx_search_wait for device callers.
@@ -209,7 +210,8 @@ typedef struct rdx_signal rdx_signal;
 int rdx_signal_create(int device, rdx_signal** out);
 int rdx_signal_destroy(rdx_signal* s);
 /* blocks until the LAST rdx_merge_topk_packed given `s` has published; *value = OR over the parts of flags[0]. `stream` = the
- * stream that merge was enqueued on (synchronised only if the word has not arrived after ~0.4 ms of spinning). */
+ * stream that merge was enqueued on: never synchronised (work enqueued behind the merge is not waited for) — the word is spun
+ * on for ~0.4 ms, then polled between short sleeps, and the stream is only queried now and then to report a lost merge. */
 int rdx_signal_wait(rdx_signal* s, void* stream, int32_t* value);
 
 /* Same merge, reading the partials straight out of the all-gather receive buffer (device memory):

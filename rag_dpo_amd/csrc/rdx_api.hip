@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <sched.h>
 #include <unordered_map>
 #include <vector>
 
@@ -839,31 +840,43 @@ static int ensure_pin_out(rdx_index* h, size_t bytes) {
 // The search numbered `seq` has completed: its k_finish published the mailbox. Spin on the pinned word for a while
 // (short searches: the store arrives a couple of us after the kernel, no interrupt, no D2H copy), then fall back to
 // hipStreamSynchronize (long searches; it also surfaces a faulted kernel).
-// Waits for THIS search's mailbox word, never for the stream: an asynchronous caller may have enqueued other work behind the
-// search (BASELINE config 5: the next batch's query encode, 15 ms of kernels), and a stream synchronise would wait for that too.
-// Hot spin for 0.4 ms (a small search ends inside it), then poll between 20 us sleeps; the stream is only QUERIED, every 50 ms,
-// to turn a failed or vanished search into an error instead of an endless wait.
-static int wait_search(rdx_index* h, hipStream_t st, unsigned long long seq) {
+// Waits until ready() says a word in pinned host memory has arrived — never for the stream: an asynchronous caller may have enqueued
+// other work behind the search or merge that publishes the word (BASELINE config 5: the next batch's query encode, 15 ms of kernels),
+// and a stream synchronise would wait for that too. Hot spin for 0.4 ms (a small search ends inside it), then poll with a yield
+// between looks (a 0.6 - 25 ms search is noticed within a microsecond; measured with 20 us sleeps instead: +30 us on a 0.56 ms search,
+// +170 us on a 2.2 ms one), after 200 ms with 50 us sleeps. The stream is only QUERIED, every 50 ms, to turn a failed or vanished
+// launch into an error instead of an endless wait. 0 = arrived, 1 = the stream ran dry without the word, < 0 = error code.
+template <class F>
+static int wait_word(F ready, hipStream_t st) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
-        if (__atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) == seq) return RDX_OK;
+        if (ready()) return 0;
         _mm_pause();
         if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
     }
-    auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
-    for (;;) {
-        if (__atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) == seq) return RDX_OK;
-        std::this_thread::sleep_for(std::chrono::microseconds(20));
-        if (std::chrono::steady_clock::now() >= next_query) {
+    auto next_query = t0 + std::chrono::milliseconds(50);
+    const auto t_sleep = t0 + std::chrono::milliseconds(200);
+    for (unsigned n = 1;; ++n) {
+        if (ready()) return 0;
+        if ((n & 15u) != 0) {
+            sched_yield();
+            continue;
+        }
+        const auto now = std::chrono::steady_clock::now();
+        if (now >= t_sleep) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (now >= next_query) {
             const hipError_t e = hipStreamQuery(st);
-            if (e == hipSuccess) {   // everything enqueued has run: the word must be there
-                if (__atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) == seq) return RDX_OK;
-                return fail(RDX_ERR_HIP, "internal: the search completed without publishing its mailbox");
-            }
+            if (e == hipSuccess) return ready() ? 0 : 1;   // everything enqueued has run: the word must be there
             if (e != hipErrorNotReady) return fail(RDX_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
-            next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
+            next_query = now + std::chrono::milliseconds(50);
         }
     }
+}
+
+static int wait_search(rdx_index* h, hipStream_t st, unsigned long long seq) {
+    const int rc = wait_word([&] { return __atomic_load_n(&h->mbox->seq, __ATOMIC_ACQUIRE) == seq; }, st);
+    if (rc == 1) return fail(RDX_ERR_HIP, "internal: the search completed without publishing its mailbox");
+    return rc;
 }
 
 // depth 0 = the caller's batch; depth 1 = the second-chance batch of queries whose candidate segments overflowed
@@ -1683,20 +1696,11 @@ extern "C" int rdx_signal_destroy(rdx_signal* s) {
 extern "C" int rdx_signal_wait(rdx_signal* s, void* stream, int32_t* value) {
     if (!s || !value) return fail(RDX_ERR_INVALID, "rdx_signal_wait: null pointer");
     if (s->seq == 0) return fail(RDX_ERR_STATE, "rdx_signal_wait: no merge has been given this signal");
-    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(s->device));
     unsigned long long w = 0;
-    for (unsigned spins = 1;; ++spins) {
-        w = __atomic_load_n(s->host, __ATOMIC_ACQUIRE);
-        if ((w >> 1) == s->seq) break;
-        _mm_pause();
-        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
-            HIP_TRY(hipSetDevice(s->device));
-            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-            w = __atomic_load_n(s->host, __ATOMIC_ACQUIRE);
-            if ((w >> 1) != s->seq) return fail(RDX_ERR_HIP, "internal: the merge completed without publishing its signal");
-            break;
-        }
-    }
+    const int rc = wait_word([&] { return ((w = __atomic_load_n(s->host, __ATOMIC_ACQUIRE)) >> 1) == s->seq; }, (hipStream_t)stream);
+    if (rc == 1) return fail(RDX_ERR_HIP, "internal: the merge completed without publishing its signal");
+    if (rc != 0) return rc;
     *value = (int32_t)(w & 1ull);
     return RDX_OK;
 }

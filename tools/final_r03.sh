@@ -10,7 +10,10 @@ cd $R
 for w in c4 c3 c2 c1; do timeout -k 10 400 python3 bench.py --workload $w > $O/$w.json 2> $O/$w.err || echo "bench $w failed"; done
 echo "benches done"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu > $O/c5.json 2> $O/c5.err || echo "bench c5 failed"
-timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --enc-buckets 1 > $O/c5_one_forward.json 2> /dev/null || echo "bench c5 1 bucket failed"
+timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --enc-torch-ops > $O/c5_torch_ops.json 2> /dev/null || echo "bench c5 torch ops failed"
+timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --enc-module-forward > $O/c5_module_forward.json 2> /dev/null || echo "bench c5 module failed"
+timeout -k 10 400 python3 bench.py --workload c5 --no-cpu > $O/c5_again.json 2> /dev/null || echo "bench c5 again failed"
+timeout -k 10 300 python3 tools/enc_ab.py 2>&1 | grep -v amdgpu.ids > $O/c5_encode_gpu_time.txt || echo "enc_ab failed"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --no-encode > $O/c5_noenc.json 2> /dev/null || echo "bench c5 noenc failed"
 timeout -k 10 400 python3 bench.py --workload c4 --no-cpu --set spec_tau=0 > $O/c4_nospec.json 2> /dev/null || echo "bench c4 nospec failed"
 timeout -k 10 400 python3 bench.py --workload c3 --no-cpu --set spec_tau=0 > $O/c3_nospec.json 2> /dev/null || echo "bench c3 nospec failed"
@@ -54,6 +57,16 @@ with open(sys.argv[2], "w", newline="") as f:
 PY
   rm -rf $O/trace_$w
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_enc -- python3 $R/tools/enc_fused_only.py 20 > /dev/null 2> $O/trace_enc.err || echo "trace enc failed"
+f=$(ls $O/trace_enc/*/*kernel_stats.csv | head -1); python3 - "$f" "$O/c5_encode_kernel_stats.csv" <<'PY'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+with open(sys.argv[2], "w", newline="") as f:
+    w = csv.writer(f, quoting=csv.QUOTE_ALL)
+    for r in rows[:16]:
+        w.writerow([r[0][:140]] + r[1:])
+PY
+rm -rf $O/trace_enc
 echo "traces done"
 cd $R
 timeout -k 10 400 bash tools/pmc.sh r03sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" > $O/sq_grbm_2Mrows_pmc.txt 2>&1 || echo "pmc failed"

@@ -4,8 +4,8 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03_encprof
 mkdir -p $O && cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/tools/enc_profile.py > $O/out.txt 2>&1 || { tail -20 $O/out.txt; exit 1; }
-head -12 $O/out.txt
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/tools/enc_fused_only.py 20 > $O/out.txt 2>&1 || { tail -20 $O/out.txt; exit 1; }
+tail -1 $O/out.txt
 f=$(ls $O/prof/*/*_kernel_stats.csv | head -1)
 cp $f $O/kernel_stats.csv
 python3 - <<PY

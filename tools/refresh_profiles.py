@@ -6,8 +6,7 @@ bench_dir, tag, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
 dst = os.path.join(R, "profiles", rnd)
 src = os.path.join(R, "gpurun_out", f"prof_{tag}")
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(dst + "/*"):
-    os.remove(f)
+# files of an earlier call that this run does not produce again stay (profiles/README.md says which call each file is from)
 rows = list(csv.reader(open(glob.glob(src + "/trace/*/*_kernel_stats.csv")[0])))
 with open(dst + "/c4_n1_kernel_stats.csv", "w", newline="") as f:
     w = csv.writer(f, quoting=csv.QUOTE_ALL)
