@@ -312,7 +312,7 @@ def test_fused_encoder_kernels_equal_the_torch_operations():
 
     fast, plain, module = make(None), make(False), make(False, packed=False)
     assert fast._packed.fused and not plain._packed.fused and module._packed is None
-    for texts in (short, long_):
+    for texts in (short, long_, ["w1 w2 w3 w4 w5 w6 w7"]):             # (the last: ONE question, the reference's embed_query)
         a, b, c = (torch.nn.functional.normalize(p.embed_device(texts).float(), dim=1) for p in (fast, plain, module))   # (raw CLS rows: the index normalises)
         torch.cuda.synchronize()
         for other in (b, c):

@@ -533,6 +533,28 @@ def test_split_k_bootstrap(eng, oracle, d, n, b, k):
     assert seen[1]["sample_rows"] % 32 == 0 and seen[1]["sample_rows"] >= min(n // 32 * 32, 8192) or n < 8192, seen
 
 
+def test_small_scan_path_through_ties(eng, oracle):
+    """the split-K path of small searches (k_boot, k_scan_small, k_refine on short candidate lists) when the k-th score is shared by
+    identical rows: 8 copies of a row near every query, k = 5, 8 and 12 (ties go to the lowest row id), and k above the number of
+    rows a bitmap leaves. Same ids and score bits as the oracle, with the split-K main scan and with the tile kernel."""
+    n, d, b = 50_000, 256, 16
+    rng = np.random.default_rng(31)
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((b, d)).astype(np.float32)
+    for j in range(b):
+        twin = (q[j] + 0.05 * rng.standard_normal(d)).astype(np.float32)
+        corpus[rng.choice(n, size=8, replace=False)] = twin
+    allow = np.zeros(n, dtype=bool)
+    allow[rng.choice(n, size=40, replace=False)] = True
+    for ss in (1, 0):
+        ix = _index(eng, corpus, force_fast=1, small_scan=ss)
+        for k in (5, 8, 12):
+            st = _check(oracle, ix, corpus, q, k, expect_path=0)
+            assert st["exact_queries"] == 0, (ss, k, st)
+        _check(oracle, ix, corpus, q, 50, allow, expect_path=0)       # 40 allowed rows, k = 50
+        ix.close()
+
+
 def test_speculative_threshold_is_verified(eng, oracle):
     """option spec_tau (default on): the scan threshold comes from a rank below k of the sampled scores — an estimate, not a bound —
     and k_refine verifies it per query. (1) On a random corpus the rank IS below k and the answers are the oracle's. (2) A corpus
