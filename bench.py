@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / recall leg")
     ap.add_argument("--no-encode", action="store_true", help="c5: leave the BGE-M3 query encode out of the step")
     ap.add_argument("--enc-buckets", type=int, default=4, help="c5: most length buckets (forwards) per encoded batch; 1 = one forward padded to the longest text")
+    ap.add_argument("--enc-graphs", action="store_true", help="c5: replay the fused encoder forward as a HIP graph (one launch per encode)")
     ap.add_argument("--enc-torch-ops", action="store_true", help="c5: the packed forward on torch operations only (without librdx's attention and add + LayerNorm kernels)")
     ap.add_argument("--enc-module-forward", action="store_true", help="c5: the checkpoint's module-by-module forward over the padded batch instead of the packed forward")
     ap.add_argument("--no-overlap", action="store_true", help="c5: encode then search on one stream (no pipelining of batch i+1's encode with batch i's search)")
@@ -293,6 +294,7 @@ def main():
         provider.packed_forward = not args.enc_module_forward
         if args.enc_torch_ops:
             provider.fused_kernels = False
+        provider.encoder_graphs = args.enc_graphs
         provider.load()
         provider.max_buckets = max(1, args.enc_buckets)
         texts = synth.query_texts(B)

@@ -846,13 +846,17 @@ static int ensure_pin_out(rdx_index* h, size_t bytes) {
 // between looks (a 0.6 - 25 ms search is noticed within a microsecond; measured with 20 us sleeps instead: +30 us on a 0.56 ms search,
 // +170 us on a 2.2 ms one), after 200 ms with 50 us sleeps. The stream is only QUERIED, every 50 ms, to turn a failed or vanished
 // launch into an error instead of an endless wait. 0 = arrived, 1 = the stream ran dry without the word, < 0 = error code.
+static int g_wait_spin_us = [] {   // developer knob: how long the hot spin lasts before the polite poll takes over
+    const char* e = std::getenv("RDX_WAIT_SPIN_US");
+    return e ? std::atoi(e) : 400;
+}();
 template <class F>
 static int wait_word(F ready, hipStream_t st) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
         if (ready()) return 0;
         _mm_pause();
-        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) break;
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(g_wait_spin_us)) break;
     }
     auto next_query = t0 + std::chrono::milliseconds(50);
     const auto t_sleep = t0 + std::chrono::milliseconds(200);

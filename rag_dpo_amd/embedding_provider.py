@@ -105,6 +105,8 @@ class _PackedEncoder:
             bqkv = torch.cat([a.self.query.bias, a.self.key.bias, a.self.value.bias], 0).contiguous()
             self.layers.append((wqkv, bqkv, a.output.dense, a.output.LayerNorm, L.intermediate.dense, L.output.dense, L.output.LayerNorm))
         self._pad_buf: dict = {}
+        self._graph: dict = {}
+        self._seen: dict = {}
         # librdx's two encoder kernels (include/rdx.h: rdx_enc_attention_f16, rdx_enc_add_layernorm_f16) take the place of the
         # scatter -> padded attention -> transposing copy -> gather chain and of the add + LayerNorm pairs: fp16 on a GPU, 64-wide
         # heads, hidden a multiple of 512 up to 2048, texts up to FUSED_MAX_TOKENS tokens (the attention kernel is written for
@@ -139,10 +141,57 @@ class _PackedEncoder:
             raise RuntimeError("rdx_enc_attention_f16: " + self._last_error())
         return ctx
 
+    # HIP-graph replay of the fused forward (option, default off): captured per (texts, real tokens) shape the second time a shape is
+    # seen, replayed with ONE launch; the five small index tensors go into static device buffers first. Measured in round 3 (DESIGN.md
+    # §10): see there before switching it on.
+    graphs = False
+    MAX_GRAPHS = 4
+
+    def _fused_forward(self, tok, pos, first_d, tok_first, tok_len) -> torch.Tensor:
+        """the forward on packed tokens with librdx's two kernels: [T] ids / positions -> fp32 [B][hidden] CLS rows"""
+        F = torch.nn.functional
+        x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
+        last = len(self.layers) - 1
+        for li, (wqkv, bqkv, dense_o, ln1, inter, out, ln2) in enumerate(self.layers):
+            ctx = self._attention(F.linear(x, wqkv, bqkv), tok_first, tok_len)                                    # [T][H], no padding anywhere
+            if li == last:                                   # everything behind the last attention is row-wise: only the CLS rows are needed
+                ctx, x = ctx.index_select(0, first_d), x.index_select(0, first_d)
+            x = self._add_ln(dense_o(ctx), x, ln1)
+            x = self._add_ln(out(F.gelu(inter(x))), x, ln2)
+        return x.to(torch.float32)
+
+    def _replay(self, key, host: dict, to_dev):
+        """-> the CLS rows from a captured graph of this shape, or None (shape not captured: the caller runs eagerly)"""
+        ent = self._graph.get(key)
+        if ent is None:
+            self._seen[key] = self._seen.get(key, 0) + 1
+            if self._seen[key] < 2 or len(self._graph) >= self.MAX_GRAPHS:
+                return None
+            dev = self.layers[0][0].device
+            static = {n: torch.empty(tuple(t.shape), dtype=t.dtype, device=dev) for n, t in host.items()}
+            for n, t in host.items():
+                to_dev(n, t, static[n])
+            side = torch.cuda.Stream(device=dev)                 # one eager run on a side stream first (library workspaces), as torch asks
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._fused_forward(*(static[n] for n in self._ORDER))
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._fused_forward(*(static[n] for n in self._ORDER))
+            ent = self._graph[key] = (g, static, out)
+        g, static, out = ent
+        for n, t in host.items():
+            to_dev(n, t, static[n])
+        g.replay()
+        return out                                               # (overwritten by the next replay of this shape: consume it on the stream)
+
+    _ORDER = ("pk_tok", "pk_pos", "pk_first", "pk_tfirst", "pk_tlen")
+
     @torch.no_grad()
     def cls(self, ids: torch.Tensor, lens: np.ndarray, to_dev) -> torch.Tensor:
         """ids: [B][S] int64 on the host, right-padded; lens[b] = tokens of text b (>= 1). -> fp32 [B][hidden] CLS rows on the device.
-        to_dev(name, host tensor) -> device tensor (the provider's pinned, non-blocking copies)."""
+        to_dev(name, host tensor[, out]) -> device tensor (the provider's pinned, non-blocking copies)."""
         F = torch.nn.functional
         B, S = int(ids.shape[0]), int(ids.shape[1])
         lens = np.asarray(lens, dtype=np.int64)
@@ -151,41 +200,37 @@ class _PackedEncoder:
         row = np.repeat(np.arange(B, dtype=np.int64), lens)
         col = np.arange(T, dtype=np.int64) - np.repeat(first, lens)
         ids_np = ids.numpy()
-        tok = to_dev("pk_tok", torch.from_numpy(np.ascontiguousarray(ids_np[row, col])))
-        pos = to_dev("pk_pos", torch.from_numpy(col + (self.pad + 1)))
-        first_d = to_dev("pk_first", torch.from_numpy(first))
-        x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
+        host = {"pk_tok": torch.from_numpy(np.ascontiguousarray(ids_np[row, col])), "pk_pos": torch.from_numpy(col + (self.pad + 1)),
+                "pk_first": torch.from_numpy(first)}
         H, nh = self.hidden, self.heads
-        fused = self.fused and int(lens.max()) <= self.FUSED_MAX_TOKENS
-        if fused:
-            tok_first = to_dev("pk_tfirst", torch.from_numpy(np.repeat(first, lens).astype(np.int32)))
-            tok_len = to_dev("pk_tlen", torch.from_numpy(np.repeat(lens, lens).astype(np.int32)))
-        else:
-            flat_d = to_dev("pk_flat", torch.from_numpy(row * S + col))                                          # slot of packed token t in the padded [B*S] layout
-            kmask = to_dev("pk_mask", torch.from_numpy(np.arange(S)[None, :] < lens[:, None])).view(B, 1, 1, S)   # keys of the text itself
-            key = (B, S, x.dtype, x.device)
-            qkv_pad = self._pad_buf.get(key)
-            if qkv_pad is None:
-                if len(self._pad_buf) > 8:
-                    self._pad_buf.clear()
-                qkv_pad = self._pad_buf[key] = torch.zeros((B * S, 3 * H), dtype=x.dtype, device=x.device)   # (stale padding slots are masked keys / dropped queries)
+        if self.fused and int(lens.max()) <= self.FUSED_MAX_TOKENS:
+            host["pk_tfirst"] = torch.from_numpy(np.repeat(first, lens).astype(np.int32))
+            host["pk_tlen"] = torch.from_numpy(np.repeat(lens, lens).astype(np.int32))
+            if self.graphs:
+                out = self._replay((B, T), host, to_dev)
+                if out is not None:
+                    return out
+            return self._fused_forward(*(to_dev(n, host[n]) for n in self._ORDER))
+        tok, pos, first_d = (to_dev(n, host[n]) for n in ("pk_tok", "pk_pos", "pk_first"))
+        x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
+        flat_d = to_dev("pk_flat", torch.from_numpy(row * S + col))                                              # slot of packed token t in the padded [B*S] layout
+        kmask = to_dev("pk_mask", torch.from_numpy(np.arange(S)[None, :] < lens[:, None])).view(B, 1, 1, S)       # keys of the text itself
+        key = (B, S, x.dtype, x.device)
+        qkv_pad = self._pad_buf.get(key)
+        if qkv_pad is None:
+            if len(self._pad_buf) > 8:
+                self._pad_buf.clear()
+            qkv_pad = self._pad_buf[key] = torch.zeros((B * S, 3 * H), dtype=x.dtype, device=x.device)   # (stale padding slots are masked keys / dropped queries)
         last = len(self.layers) - 1
         for li, (wqkv, bqkv, dense_o, ln1, inter, out, ln2) in enumerate(self.layers):
-            if fused:
-                ctx = self._attention(F.linear(x, wqkv, bqkv), tok_first, tok_len)                                # [T][H], no padding anywhere
-            else:
-                qkv_pad.index_copy_(0, flat_d, F.linear(x, wqkv, bqkv))
-                q, k, v = qkv_pad.view(B, S, 3, nh, H // nh).permute(2, 0, 3, 1, 4)                               # [B][heads][S][head_dim] views
-                ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=kmask)
-                ctx = ctx.transpose(1, 2).reshape(B * S, H).index_select(0, flat_d)                               # back to [T][H]
+            qkv_pad.index_copy_(0, flat_d, F.linear(x, wqkv, bqkv))
+            q, k, v = qkv_pad.view(B, S, 3, nh, H // nh).permute(2, 0, 3, 1, 4)                                   # [B][heads][S][head_dim] views
+            ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=kmask)
+            ctx = ctx.transpose(1, 2).reshape(B * S, H).index_select(0, flat_d)                                   # back to [T][H]
             if li == last:                                   # everything behind the last attention is row-wise: only the CLS rows are needed
                 ctx, x = ctx.index_select(0, first_d), x.index_select(0, first_d)
-            if fused:
-                x = self._add_ln(dense_o(ctx), x, ln1)
-                x = self._add_ln(out(F.gelu(inter(x))), x, ln2)
-            else:
-                x = ln1(dense_o(ctx) + x)
-                x = ln2(out(F.gelu(inter(x))) + x)
+            x = ln1(dense_o(ctx) + x)
+            x = ln2(out(F.gelu(inter(x))) + x)
         return x.to(torch.float32)
 
 
@@ -268,6 +313,7 @@ class EmbeddingProvider:
             try:
                 fused = self.fused_kernels if self.fused_kernels is not None else (str(self.device).startswith("cuda") and self.dtype == torch.float16)
                 self._packed = _PackedEncoder(self._model, fused=bool(fused))
+                self._packed.graphs = bool(self.encoder_graphs) and self._packed.fused
             except ValueError as e:                                           # another architecture: the module forward stays
                 logger.info(f"packed forward not available for this model ({e}); using the module forward")
         logger.info(f"{self.model_name} loaded in {time.time() - t0:.1f}s (dims={self._dims})")
@@ -285,6 +331,7 @@ class EmbeddingProvider:
     # 1024 query texts to one call) one batch means one width: 8-24-word questions padded to the longest are ~30 % padding
     # tokens. A batch is therefore cut, after tokenising, into at most `max_buckets` buckets of consecutive (token-count-sorted)
     # rows, each forwarded at its own width; the cuts (multiples of 64 rows) minimise padded tokens + a per-forward charge.
+    encoder_graphs = False             # True: the fused forward is captured per (texts, tokens) shape and replayed as one HIP graph (_PackedEncoder.graphs)
     fused_kernels: Optional[bool] = None   # None: librdx's encoder kernels whenever the provider runs fp16 on a GPU (the library must load); False: torch operations only
     packed_forward = True              # _PackedEncoder: token-wise layers over the real tokens only (padding only around the attention)
     max_buckets = 4
@@ -295,7 +342,7 @@ class EmbeddingProvider:
     time_buckets = False               # True: CUDA events around every bucket's forward (last_encode_stats["buckets"][i]["ms"])
     last_encode_stats: Optional[dict] = None
 
-    def _h2d(self, name: str, t: torch.Tensor) -> torch.Tensor:
+    def _h2d(self, name: str, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """small host tensor -> device WITHOUT blocking the host: through pinned staging buffers (a ring of PIN_RING per name and
         shape, each guarded by an event: it is not overwritten before the copy that read it last has run). A pageable
         `.to(device)` is a synchronous copy: it parks the host until everything enqueued on the stream so far — the previous batch's
@@ -304,7 +351,7 @@ class EmbeddingProvider:
         buffer waits for belongs to the encode before the previous one — with a single buffer the "rows" copy at the END of encode i
         made the host wait for the whole of encode i before it could issue encode i+1 (measured: 12 of 17 ms of host time per step)."""
         if not str(self.device).startswith("cuda"):
-            return t.to(self.device)
+            return t.to(self.device) if out is None else out.copy_(t)
         key = (name, tuple(t.shape), t.dtype)
         ent = self._pinned.get(key)
         if ent is None:
@@ -317,7 +364,7 @@ class EmbeddingProvider:
         if ev is not None:
             ev.synchronize()
         buf.copy_(t)
-        d = buf.to(self.device, non_blocking=True)
+        d = buf.to(self.device, non_blocking=True) if out is None else out.copy_(buf, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         slot[1] = ev

@@ -312,6 +312,15 @@ def test_fused_encoder_kernels_equal_the_torch_operations():
 
     fast, plain, module = make(None), make(False), make(False, packed=False)
     assert fast._packed.fused and not plain._packed.fused and module._packed is None
+    replayed = EmbeddingProvider(model_name="random-init:mid", device="cuda:0", dtype=torch.float16, batch_size=512)
+    replayed.encoder_graphs = True                         # the fused forward as a HIP graph: eager, capture + replay, replay
+    replayed.load()
+    want = fast.embed_device(short).clone()
+    runs = [replayed.embed_device(short).clone() for _ in range(3)]
+    assert len(replayed._packed._graph) == 1
+    for r in runs:
+        assert float((torch.nn.functional.normalize(r, dim=1) - torch.nn.functional.normalize(want, dim=1)).abs().max()) <= 2e-3
+    assert torch.equal(runs[1], runs[2])
     for texts in (short, long_, ["w1 w2 w3 w4 w5 w6 w7"]):             # (the last: ONE question, the reference's embed_query)
         a, b, c = (torch.nn.functional.normalize(p.embed_device(texts).float(), dim=1) for p in (fast, plain, module))   # (raw CLS rows: the index normalises)
         torch.cuda.synchronize()

@@ -6,12 +6,17 @@ from rag_dpo_amd import synth
 from rag_dpo_amd.embedding_provider import EmbeddingProvider
 texts = synth.query_texts(1024)
 prov = {}
-for name, packed, fused in (("fused", True, None), ("packed", True, False), ("module", False, False)):
+import os
+variants = [("fused", True, None, False), ("packed", True, False, False), ("module", False, False, False)]
+if os.environ.get("ENC_AB_GRAPH"):
+    variants.insert(1, ("graph", True, None, True))
+for name, packed, fused, graphs in variants:
     p = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device="cuda:0", dtype=torch.float16, batch_size=1024)
-    p.packed_forward, p.fused_kernels = packed, fused
+    p.packed_forward, p.fused_kernels, p.encoder_graphs = packed, fused, graphs
     prov[name] = p.load()
 b = prov["module"].embed_device(texts)
-for name in ("fused", "packed"):
+for name in [v[0] for v in variants if v[0] != "module"]:
+    prov[name].embed_device(texts); prov[name].embed_device(texts)      # (a graph is captured the second time a shape is seen)
     a = prov[name].embed_device(texts)
     torch.cuda.synchronize()
     na, nb = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(b, dim=1)
