@@ -7,9 +7,10 @@ Reference behaviour mirrored (file:line in /root/reference/src/utils/embedding_p
   embed(texts): [] -> []; char-truncate 20 000; encode batch; L2-normalise; tolist  :118-147
   embed_query, is_available, get_info, __repr__                                     :149-185
 
-What differs underneath: the transformer forward is plain PyTorch-ROCm (plumbing: `transformers.XLMRobertaModel`,
-CLS pooling as BGE-M3's dense head) and the L2-normalise is librdx K1 on the device (`rdx_l2_normalize`, the same
-arithmetic the index uses for corpus rows). Weights and tokenizer are loaded ONLY from a local directory
+What differs underneath: the transformer forward runs over the checkpoint's `transformers.XLMRobertaModel` weights on the packed
+real tokens of a batch (`_PackedEncoder`: GEMMs and GELU are PyTorch-ROCm plumbing; on a GPU in fp16 the attention and the
+add + LayerNorm pairs are librdx kernels, `rdx_enc_attention_f16` / `rdx_enc_add_layernorm_f16`), CLS pooling as BGE-M3's dense
+head, and the L2-normalise is librdx K1 on the device (`rdx_l2_normalize`, the same arithmetic the index uses for corpus rows). Weights and tokenizer are loaded ONLY from a local directory
 (`model_name` itself, or `<cache_dir>/<model_name>` / HF-cache layout): this build never fetches by name
 (no network; HF_HUB_OFFLINE). `model_name="random-init:xlm-roberta-large"` builds the BGE-M3 architecture with
 random weights and a hashing tokenizer — shape/perf faithful for benchmarks, NOT value faithful
