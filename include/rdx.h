@@ -145,11 +145,14 @@ int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out
  *   key and value rows (heads x head_dim each, head-major); token t belongs to the text whose tokens are
  *   tok_first[t] .. tok_first[t] + tok_len[t] - 1 (tok_len >= 1) and attends to exactly those. ctx [n_tokens][heads*head_dim] =
  *   softmax(q k^T * scale) v per head, soft-max and accumulation in fp32. head_dim must be 64. Meant for short texts
- *   (questions): the work per token grows with its text's length.
+ *   (questions): the work per token grows with its text's length. max_text_tokens: the longest text's token count if the caller
+ *   knows it (sizes the LDS window a workgroup stages keys in; a wrong or unknown value — pass 0 — costs speed only: rows whose
+ *   text does not fit the window read global memory).
  * rdx_enc_add_layernorm_f16: out[r] = LayerNorm(a[r] + b[r]) * gamma + beta over rows of `hidden` halves (512, 1024, 1536 or
  *   2048; biased variance, fp32 statistics, the sum rounded to fp16 first — what an fp16 add followed by LayerNorm computes). */
 int rdx_enc_attention_f16(int device, const void* qkv, const int32_t* tok_first, const int32_t* tok_len,
-                          int64_t n_tokens, int heads, int head_dim, float scale, void* ctx, void* stream);
+                          int64_t n_tokens, int heads, int head_dim, float scale, int max_text_tokens, void* ctx,
+                          void* stream);
 int rdx_enc_add_layernorm_f16(int device, const void* a, const void* b, const void* gamma, const void* beta,
                               float eps, int64_t rows, int hidden, void* out, void* stream);
 

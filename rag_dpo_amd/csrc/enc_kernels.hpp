@@ -58,7 +58,8 @@ __device__ __forceinline__ float dot16(const h8& q0, const h8& q1, const h8& k0,
     return quad_swap_add<0x4E>(s);   // quad_perm [2,3,0,1]
 }
 
-constexpr int ENC_KEY_WINDOW = 192;   // keys (and values) of one head a workgroup stages in LDS: 64 rows of texts up to 64 tokens need <= 190
+constexpr int ENC_KEY_WINDOW = 192;   // most keys (and values) of one head a workgroup stages in LDS: 64 rows of texts up to 64 tokens need <= 190;
+                                      // texts up to L tokens need 64 + 2 (L - 1): the host passes that (less LDS per workgroup = more of them per CU)
 
 // One row's attention over the S keys at `kv` (key j: 16 of its 64 dims at kv + j * STRIDE halves, its value VOFF halves further).
 // Two keys per iteration: one running-max update and one rescale of the 16 accumulators for both (an odd text's last iteration
@@ -97,8 +98,9 @@ __device__ __forceinline__ void attend_row(P kv, int64_t stride, int64_t voff, i
 // the kernel is meant for) read global memory instead: same arithmetic.
 __global__ __launch_bounds__(256) void k_enc_attention(const _Float16* __restrict__ qkv, const int32_t* __restrict__ tok_first,
                                                        const int32_t* __restrict__ tok_len, int64_t T, int heads, float scale,
-                                                       _Float16* __restrict__ ctx) {
-    __shared__ __attribute__((aligned(16))) _Float16 kv_s[ENC_KEY_WINDOW * 128];   // [key][K 64 | V 64]
+                                                       int window, _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char enc_smem[];
+    _Float16* kv_s = reinterpret_cast<_Float16*>(enc_smem);   // [window][K 64 | V 64]; the host sizes the window from the longest text
     const int g = threadIdx.x & 3;
     const int64_t t0 = (int64_t)blockIdx.x * 64;
     const int64_t t = t0 + (threadIdx.x >> 2);
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_enc_attention(const _Float16* __restric
     const int64_t tl = t0 + 63 < T ? t0 + 63 : T - 1;
     const int64_t kfirst = tok_first[t0];
     const int64_t kend = (int64_t)tok_first[tl] + tok_len[tl];
-    const int nk = (int)(kend - kfirst < ENC_KEY_WINDOW ? kend - kfirst : ENC_KEY_WINDOW);
+    const int nk = (int)(kend - kfirst < window ? kend - kfirst : window);
     for (int c = threadIdx.x; c < nk * 16; c += 256) {
         const int tok = c >> 4, part = c & 15;   // 16-byte pieces 0..7: the key's 64 dims, 8..15: the value's
         const _Float16* src = qkv + (kfirst + tok) * row + H * (1 + (part >> 3)) + h * ENC_HEAD_DIM + (part & 7) * 8;

@@ -636,7 +636,7 @@ struct NormScratch {
 static NormScratch* const g_norm = new NormScratch[64];
 
 extern "C" int rdx_enc_attention_f16(int device, const void* qkv, const int32_t* tok_first, const int32_t* tok_len, int64_t n_tokens,
-                                     int heads, int head_dim, float scale, void* ctx, void* stream) {
+                                     int heads, int head_dim, float scale, int max_text_tokens, void* ctx, void* stream) {
     if (n_tokens < 0 || heads < 1 || heads > 65535) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: bad shape");
     if (head_dim != ENC_HEAD_DIM) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: head_dim must be 64");
     if (n_tokens == 0) return RDX_OK;
@@ -644,8 +644,11 @@ extern "C" int rdx_enc_attention_f16(int device, const void* qkv, const int32_t*
     if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: qkv and ctx must be 16-byte aligned");
     if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_attention_f16: device out of range");
     HIP_TRY(hipSetDevice(device));
-    hipLaunchKernelGGL(k_enc_attention, dim3((unsigned)((n_tokens + 63) / 64), (unsigned)heads), dim3(256), 0, (hipStream_t)stream,
-                       (const _Float16*)qkv, tok_first, tok_len, n_tokens, heads, scale, (_Float16*)ctx);
+    // keys a workgroup stages in LDS: its 64 tokens' texts span at most 64 + 2 (L - 1) tokens when no text is longer than L
+    int window = ENC_KEY_WINDOW;
+    if (max_text_tokens > 0) window = std::min<int64_t>(ENC_KEY_WINDOW, (64 + 2 * ((int64_t)max_text_tokens - 1) + 7) / 8 * 8);
+    hipLaunchKernelGGL(k_enc_attention, dim3((unsigned)((n_tokens + 63) / 64), (unsigned)heads), dim3(256), (size_t)window * 256, (hipStream_t)stream,
+                       (const _Float16*)qkv, tok_first, tok_len, n_tokens, heads, scale, window, (_Float16*)ctx);
     HIP_TRY(hipGetLastError());
     return RDX_OK;
 }

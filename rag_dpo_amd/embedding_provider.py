@@ -132,11 +132,11 @@ class _PackedEncoder:
             raise RuntimeError("rdx_enc_add_layernorm_f16: " + self._last_error())
         return out
 
-    def _attention(self, qkv: torch.Tensor, tok_first: torch.Tensor, tok_len: torch.Tensor) -> torch.Tensor:
+    def _attention(self, qkv: torch.Tensor, tok_first: torch.Tensor, tok_len: torch.Tensor, max_len: int) -> torch.Tensor:
         T = qkv.shape[0]
         ctx = torch.empty((T, self.hidden), dtype=qkv.dtype, device=qkv.device)
         rc = self._lib.rdx_enc_attention_f16(qkv.device.index or 0, qkv.data_ptr(), tok_first.data_ptr(), tok_len.data_ptr(), T, self.heads,
-                                             self.hidden // self.heads, (self.hidden // self.heads) ** -0.5, ctx.data_ptr(),
+                                             self.hidden // self.heads, (self.hidden // self.heads) ** -0.5, int(max_len), ctx.data_ptr(),
                                              torch.cuda.current_stream(qkv.device).cuda_stream)
         if rc:
             raise RuntimeError("rdx_enc_attention_f16: " + self._last_error())
@@ -148,20 +148,20 @@ class _PackedEncoder:
     graphs = False
     MAX_GRAPHS = 4
 
-    def _fused_forward(self, tok, pos, first_d, tok_first, tok_len) -> torch.Tensor:
+    def _fused_forward(self, tok, pos, first_d, tok_first, tok_len, max_len: int = 0) -> torch.Tensor:
         """the forward on packed tokens with librdx's two kernels: [T] ids / positions -> fp32 [B][hidden] CLS rows"""
         F = torch.nn.functional
         x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
         last = len(self.layers) - 1
         for li, (wqkv, bqkv, dense_o, ln1, inter, out, ln2) in enumerate(self.layers):
-            ctx = self._attention(F.linear(x, wqkv, bqkv), tok_first, tok_len)                                    # [T][H], no padding anywhere
+            ctx = self._attention(F.linear(x, wqkv, bqkv), tok_first, tok_len, max_len)                           # [T][H], no padding anywhere
             if li == last:                                   # everything behind the last attention is row-wise: only the CLS rows are needed
                 ctx, x = ctx.index_select(0, first_d), x.index_select(0, first_d)
             x = self._add_ln(dense_o(ctx), x, ln1)
             x = self._add_ln(out(F.gelu(inter(x))), x, ln2)
         return x.to(torch.float32)
 
-    def _replay(self, key, host: dict, to_dev):
+    def _replay(self, key, host: dict, to_dev, max_len: int):
         """-> the CLS rows from a captured graph of this shape, or None (shape not captured: the caller runs eagerly)"""
         ent = self._graph.get(key)
         if ent is None:
@@ -175,11 +175,11 @@ class _PackedEncoder:
             side = torch.cuda.Stream(device=dev)                 # one eager run on a side stream first (library workspaces), as torch asks
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                self._fused_forward(*(static[n] for n in self._ORDER))
+                self._fused_forward(*(static[n] for n in self._ORDER), max_len)
             torch.cuda.current_stream(dev).wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self._fused_forward(*(static[n] for n in self._ORDER))
+                out = self._fused_forward(*(static[n] for n in self._ORDER), max_len)
             ent = self._graph[key] = (g, static, out)
         g, static, out = ent
         for n, t in host.items():
@@ -207,11 +207,12 @@ class _PackedEncoder:
         if self.fused and int(lens.max()) <= self.FUSED_MAX_TOKENS:
             host["pk_tfirst"] = torch.from_numpy(np.repeat(first, lens).astype(np.int32))
             host["pk_tlen"] = torch.from_numpy(np.repeat(lens, lens).astype(np.int32))
+            max_len = int(lens.max())
             if self.graphs:
-                out = self._replay((B, T), host, to_dev)
+                out = self._replay((B, T, max_len), host, to_dev, max_len)   # (the longest text sizes the attention's LDS window: part of the shape)
                 if out is not None:
                     return out
-            return self._fused_forward(*(to_dev(n, host[n]) for n in self._ORDER))
+            return self._fused_forward(*(to_dev(n, host[n]) for n in self._ORDER), max_len)
         tok, pos, first_d = (to_dev(n, host[n]) for n in ("pk_tok", "pk_pos", "pk_first"))
         x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
         flat_d = to_dev("pk_flat", torch.from_numpy(row * S + col))                                              # slot of packed token t in the padded [B*S] layout

@@ -245,18 +245,21 @@ def test_encoder_attention_kernel_vs_fp32_reference():
         tl = torch.from_numpy(np.repeat(lens, lens).astype(np.int32)).cuda()
         qd = qkv.cuda()
         ctx = torch.full((T, H), float("nan"), dtype=torch.float16, device="cuda")
-        rc = L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), T, heads, 64, 0.125, ctx.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream)
-        assert rc == 0, _lib.last_error()
-        torch.cuda.synchronize()
         want = _attention_reference(qkv, [int(n) for n in lens], heads)
-        got = ctx.float().cpu()
-        assert torch.isfinite(got).all()
-        assert float((got - want).abs().max()) <= 3e-3, float((got - want).abs().max())
+        # max_text_tokens sizes the LDS window: the true maximum, unknown (0), and a too small promise (costs speed only)
+        for promise in (int(max(lens)), 0, 2):
+            ctx.fill_(float("nan"))
+            rc = L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), T, heads, 64, 0.125, promise, ctx.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, _lib.last_error()
+            torch.cuda.synchronize()
+            got = ctx.float().cpu()
+            assert torch.isfinite(got).all()
+            assert float((got - want).abs().max()) <= 3e-3, (promise, float((got - want).abs().max()))
     # argument checks: wrong head width, misaligned pointer
-    assert L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), T, heads, 32, 0.125, ctx.data_ptr(), 0) != 0
-    assert L.rdx_enc_attention_f16(0, qd.data_ptr() + 2, tf.data_ptr(), tl.data_ptr(), T, heads, 64, 0.125, ctx.data_ptr(), 0) != 0
-    assert L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), 0, heads, 64, 0.125, ctx.data_ptr(), 0) == 0
+    assert L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), T, heads, 32, 0.125, 0, ctx.data_ptr(), 0) != 0
+    assert L.rdx_enc_attention_f16(0, qd.data_ptr() + 2, tf.data_ptr(), tl.data_ptr(), T, heads, 64, 0.125, 0, ctx.data_ptr(), 0) != 0
+    assert L.rdx_enc_attention_f16(0, qd.data_ptr(), tf.data_ptr(), tl.data_ptr(), 0, heads, 64, 0.125, 0, ctx.data_ptr(), 0) == 0
 
 
 @pytest.mark.gpu
