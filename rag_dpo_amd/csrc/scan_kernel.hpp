@@ -160,7 +160,13 @@ __device__ __forceinline__ void wait_vmcnt_keep(half8 (&a)[4]) {
 template <int BN, int EPI, bool HAS_MASK, bool RES, bool SIBT = false, bool NTT = false, bool FUSEDT = false>
 __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     constexpr bool FUSED = FUSEDT && EPI == EPI_EMIT;
+#ifdef RDX_NT_ALL   // developer A/B (tools/ab_lib.py): non-temporal corpus loads also when several query tiles share a corpus tile through L2.
+                    // Measured at 10 M x 1024, B = 1024 (round 3, same box, three alternating rounds): 58.9 k against 66.1 k queries/s, fabric
+                    // reads per launch 1.74 x — the sibling workgroups stop finding the tile in L2. Plain loads stay.
+    constexpr bool NT_A = true;
+#else
     constexpr bool NT_A = RDX_NT_SMALL && NTT;   // host: NTT launches have ONE query tile (every corpus byte is read by one workgroup)
+#endif
     constexpr int LATE_NUM = FUSED ? RDX_DMA_LATE_NUM_FUSED : RDX_DMA_LATE_NUM;   // where the late half issues its DMA (see `step`)
     constexpr int B_BYTES = BN * BK * 2;  // one k-step image of this workgroup's queries
     constexpr int NPB = BN / 64;          // 1 KiB DMA pieces per wave per query image
