@@ -294,7 +294,7 @@ def main():
         provider.packed_forward = not args.enc_module_forward
         if args.enc_torch_ops:
             provider.fused_kernels = False
-        provider.encoder_graphs = args.enc_graphs
+        provider.encoder_graphs = True if args.enc_graphs else None
         provider.load()
         provider.max_buckets = max(1, args.enc_buckets)
         texts = synth.query_texts(B)

@@ -142,11 +142,14 @@ class _PackedEncoder:
             raise RuntimeError("rdx_enc_attention_f16: " + self._last_error())
         return ctx
 
-    # HIP-graph replay of the fused forward (option, default off): captured per (texts, real tokens) shape the second time a shape is
-    # seen, replayed with ONE launch; the five small index tensors go into static device buffers first. Measured in round 3 (DESIGN.md
-    # §10): see there before switching it on.
-    graphs = False
-    MAX_GRAPHS = 4
+    # HIP-graph replay of the fused forward: captured per (texts, real tokens, longest text) shape the second time a shape is seen,
+    # replayed with ONE launch; the five small index tensors go into static device buffers first. graphs = "auto" (default): batches
+    # of ONE text only — the reference's online path, embed_query(): its ~200 tiny kernels are pure launch latency (measured, one
+    # question on XLM-R-large fp16: module forward 5.65 ms, this forward eager 3.01, replayed 1.55), and questions come in a few dozen
+    # lengths, so the shapes repeat. True: every batch the kernels serve (a batch of 1024 gains nothing on the GPU, 3 ms of host
+    # time; production batches rarely repeat a token count). False: never. At most MAX_GRAPHS shapes are kept (least recently used out).
+    graphs = "auto"
+    MAX_GRAPHS = 64
 
     def _fused_forward(self, tok, pos, first_d, tok_first, tok_len, max_len: int = 0) -> torch.Tensor:
         """the forward on packed tokens with librdx's two kernels: [T] ids / positions -> fp32 [B][hidden] CLS rows"""
@@ -163,11 +166,15 @@ class _PackedEncoder:
 
     def _replay(self, key, host: dict, to_dev, max_len: int):
         """-> the CLS rows from a captured graph of this shape, or None (shape not captured: the caller runs eagerly)"""
-        ent = self._graph.get(key)
+        ent = self._graph.pop(key, None)
         if ent is None:
+            if len(self._seen) > 4096:
+                self._seen.clear()
             self._seen[key] = self._seen.get(key, 0) + 1
-            if self._seen[key] < 2 or len(self._graph) >= self.MAX_GRAPHS:
+            if self._seen[key] < 2:
                 return None
+            while len(self._graph) >= self.MAX_GRAPHS:
+                self._graph.pop(next(iter(self._graph)))          # least recently used (dicts keep insertion order; a hit re-inserts)
             dev = self.layers[0][0].device
             static = {n: torch.empty(tuple(t.shape), dtype=t.dtype, device=dev) for n, t in host.items()}
             for n, t in host.items():
@@ -180,7 +187,8 @@ class _PackedEncoder:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self._fused_forward(*(static[n] for n in self._ORDER), max_len)
-            ent = self._graph[key] = (g, static, out)
+            ent = (g, static, out)
+        self._graph[key] = ent
         g, static, out = ent
         for n, t in host.items():
             to_dev(n, t, static[n])
@@ -208,7 +216,7 @@ class _PackedEncoder:
             host["pk_tfirst"] = torch.from_numpy(np.repeat(first, lens).astype(np.int32))
             host["pk_tlen"] = torch.from_numpy(np.repeat(lens, lens).astype(np.int32))
             max_len = int(lens.max())
-            if self.graphs:
+            if self.graphs is True or (self.graphs == "auto" and B == 1):
                 out = self._replay((B, T, max_len), host, to_dev, max_len)   # (the longest text sizes the attention's LDS window: part of the shape)
                 if out is not None:
                     return out
@@ -315,7 +323,7 @@ class EmbeddingProvider:
             try:
                 fused = self.fused_kernels if self.fused_kernels is not None else (str(self.device).startswith("cuda") and self.dtype == torch.float16)
                 self._packed = _PackedEncoder(self._model, fused=bool(fused))
-                self._packed.graphs = bool(self.encoder_graphs) and self._packed.fused
+                self._packed.graphs = "auto" if self.encoder_graphs is None else bool(self.encoder_graphs)
             except ValueError as e:                                           # another architecture: the module forward stays
                 logger.info(f"packed forward not available for this model ({e}); using the module forward")
         logger.info(f"{self.model_name} loaded in {time.time() - t0:.1f}s (dims={self._dims})")
@@ -333,7 +341,7 @@ class EmbeddingProvider:
     # 1024 query texts to one call) one batch means one width: 8-24-word questions padded to the longest are ~30 % padding
     # tokens. A batch is therefore cut, after tokenising, into at most `max_buckets` buckets of consecutive (token-count-sorted)
     # rows, each forwarded at its own width; the cuts (multiples of 64 rows) minimise padded tokens + a per-forward charge.
-    encoder_graphs = False             # True: the fused forward is captured per (texts, tokens) shape and replayed as one HIP graph (_PackedEncoder.graphs)
+    encoder_graphs: Optional[bool] = None  # HIP-graph replay of the fused forward: None = single-text batches only (embed_query), True = every batch, False = never (_PackedEncoder.graphs)
     fused_kernels: Optional[bool] = None   # None: librdx's encoder kernels whenever the provider runs fp16 on a GPU (the library must load); False: torch operations only
     packed_forward = True              # _PackedEncoder: token-wise layers over the real tokens only (padding only around the attention)
     max_buckets = 4

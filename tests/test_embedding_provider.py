@@ -324,6 +324,18 @@ def test_fused_encoder_kernels_equal_the_torch_operations():
     for r in runs:
         assert float((torch.nn.functional.normalize(r, dim=1) - torch.nn.functional.normalize(want, dim=1)).abs().max()) <= 2e-3
     assert torch.equal(runs[1], runs[2])
+    # the default (graphs = "auto"): only ONE-text batches are replayed — embed_query(), the reference's online path
+    one = "w9 w8 w7 w6 w5"
+    singles = [fast.embed_device([one]).clone() for _ in range(3)]
+    assert len(fast._packed._graph) == 1 and fast._packed.graphs == "auto"
+    ref1 = plain.embed_device([one])
+    assert torch.equal(singles[1], singles[2])
+    assert float((torch.nn.functional.normalize(singles[2], dim=1) - torch.nn.functional.normalize(ref1, dim=1)).abs().max()) <= 2e-3
+    fast._packed.MAX_GRAPHS = 2                            # least recently used shape leaves
+    for t in ("w1", "w1 w2", "w1 w2 w3"):
+        for _ in range(2):
+            fast.embed_device([t])
+    assert len(fast._packed._graph) == 2
     for texts in (short, long_, ["w1 w2 w3 w4 w5 w6 w7"]):             # (the last: ONE question, the reference's embed_query)
         a, b, c = (torch.nn.functional.normalize(p.embed_device(texts).float(), dim=1) for p in (fast, plain, module))   # (raw CLS rows: the index normalises)
         torch.cuda.synchronize()

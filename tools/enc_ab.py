@@ -7,7 +7,7 @@ from rag_dpo_amd.embedding_provider import EmbeddingProvider
 texts = synth.query_texts(1024)
 prov = {}
 import os
-variants = [("fused", True, None, False), ("packed", True, False, False), ("module", False, False, False)]
+variants = [("fused", True, None, None), ("packed", True, False, None), ("module", False, False, None)]
 if os.environ.get("ENC_AB_GRAPH"):
     variants.insert(1, ("graph", True, None, True))
 for name, packed, fused, graphs in variants:
