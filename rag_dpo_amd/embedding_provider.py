@@ -142,14 +142,20 @@ class _PackedEncoder:
             raise RuntimeError("rdx_enc_attention_f16: " + self._last_error())
         return ctx
 
-    # HIP-graph replay of the fused forward: captured per (texts, real tokens, longest text) shape the second time a shape is seen,
-    # replayed with ONE launch; the five small index tensors go into static device buffers first. graphs = "auto" (default): batches
-    # of ONE text only — the reference's online path, embed_query(): its ~200 tiny kernels are pure launch latency (measured, one
-    # question on XLM-R-large fp16: module forward 5.65 ms, this forward eager 3.01, replayed 1.55), and questions come in a few dozen
-    # lengths, so the shapes repeat. True: every batch the kernels serve (a batch of 1024 gains nothing on the GPU, 3 ms of host
-    # time; production batches rarely repeat a token count). False: never. At most MAX_GRAPHS shapes are kept (least recently used out).
+    # HIP-graph replay of the fused forward: captured per shape the second time the shape is seen, replayed with ONE launch; the five
+    # small index tensors go into static device buffers first. graphs = "auto" (default): batches of at most SMALL_TEXTS texts — the
+    # reference's online path: embed_query(), or the <= 4 sub-queries of one question embedded together (rag_dpo_amd/retriever.py) —
+    # whose ~200 tiny kernels are pure launch latency (measured, one question on XLM-R-large fp16: module forward 6.3 ms, this
+    # forward eager 3.4, replayed 1.55). Such a batch is padded to a CANONICAL shape so that the graphs are few and always hit: real
+    # tokens up to a multiple of SMALL_TOKEN_GRANULE with one-token dummy texts (they attend to themselves; nobody reads their rows),
+    # the CLS index list up to SMALL_TEXTS entries, the longest text up to 16 / 32 / 64 (it sizes the attention's LDS window): at
+    # most 24 shapes. True: additionally every larger batch by its exact (texts, tokens, longest text) shape (a batch of 1024 gains
+    # nothing on the GPU, 3 ms of host time; production batches rarely repeat a token count). False: never. At most MAX_GRAPHS shapes
+    # are kept (least recently used out).
     graphs = "auto"
     MAX_GRAPHS = 64
+    SMALL_TEXTS = 8
+    SMALL_TOKEN_GRANULE = 32
 
     def _fused_forward(self, tok, pos, first_d, tok_first, tok_len, max_len: int = 0) -> torch.Tensor:
         """the forward on packed tokens with librdx's two kernels: [T] ids / positions -> fp32 [B][hidden] CLS rows"""
@@ -216,7 +222,19 @@ class _PackedEncoder:
             host["pk_tfirst"] = torch.from_numpy(np.repeat(first, lens).astype(np.int32))
             host["pk_tlen"] = torch.from_numpy(np.repeat(lens, lens).astype(np.int32))
             max_len = int(lens.max())
-            if self.graphs is True or (self.graphs == "auto" and B == 1):
+            if self.graphs and B <= self.SMALL_TEXTS:
+                g = self.SMALL_TOKEN_GRANULE
+                extra = -(-T // g) * g - T                       # one-token dummy texts behind the real ones
+                lb = 16 if max_len <= 16 else (32 if max_len <= 32 else 64)
+                padded = {"pk_tok": torch.cat([host["pk_tok"], torch.full((extra,), self.pad, dtype=torch.int64)]),
+                          "pk_pos": torch.cat([host["pk_pos"], torch.full((extra,), self.pad + 1, dtype=torch.int64)]),
+                          "pk_first": torch.cat([host["pk_first"], torch.zeros(self.SMALL_TEXTS - B, dtype=torch.int64)]),
+                          "pk_tfirst": torch.cat([host["pk_tfirst"], torch.arange(T, T + extra, dtype=torch.int32)]),
+                          "pk_tlen": torch.cat([host["pk_tlen"], torch.ones(extra, dtype=torch.int32)])}
+                out = self._replay(("small", T + extra, lb), padded, to_dev, lb)
+                if out is not None:
+                    return out[:B]
+            elif self.graphs is True:
                 out = self._replay((B, T, max_len), host, to_dev, max_len)   # (the longest text sizes the attention's LDS window: part of the shape)
                 if out is not None:
                     return out
@@ -341,7 +359,7 @@ class EmbeddingProvider:
     # 1024 query texts to one call) one batch means one width: 8-24-word questions padded to the longest are ~30 % padding
     # tokens. A batch is therefore cut, after tokenising, into at most `max_buckets` buckets of consecutive (token-count-sorted)
     # rows, each forwarded at its own width; the cuts (multiples of 64 rows) minimise padded tokens + a per-forward charge.
-    encoder_graphs: Optional[bool] = None  # HIP-graph replay of the fused forward: None = single-text batches only (embed_query), True = every batch, False = never (_PackedEncoder.graphs)
+    encoder_graphs: Optional[bool] = None  # HIP-graph replay of the fused forward: None = batches of up to 8 texts (embed_query, a question's sub-queries), True = every batch, False = never (_PackedEncoder.graphs)
     fused_kernels: Optional[bool] = None   # None: librdx's encoder kernels whenever the provider runs fp16 on a GPU (the library must load); False: torch operations only
     packed_forward = True              # _PackedEncoder: token-wise layers over the real tokens only (padding only around the attention)
     max_buckets = 4

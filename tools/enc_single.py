@@ -25,4 +25,14 @@ for name, p in prov.items():
     for rep in range(5):
         for t in sample: v = p.embed([t])
     emb = (time.perf_counter() - t0) / 40 * 1e3
+    four = [sample[i:i + 4] for i in (0, 4)]
+    for b4 in four:
+        for _ in range(3): p.embed_device(b4)
+    torch.cuda.synchronize()
+    l4 = []
+    for rep in range(10):
+        for b4 in four:
+            t0 = time.perf_counter(); v = p.embed_device(b4); torch.cuda.synchronize(); l4.append((time.perf_counter() - t0) * 1e3)
+    l4.sort()
+    print(f"{name:>7}: embed_device([four questions]) + synchronise: median {l4[len(l4)//2]:.3f} ms, min {l4[0]:.3f}")
     print(f"{name:>7}: embed_device([one question]) + synchronise: median {lat[len(lat)//2]:.3f} ms, min {lat[0]:.3f}, p90 {lat[int(len(lat)*0.9)]:.3f}; embed([q]) (normalise + list) {emb:.3f} ms", flush=True)
