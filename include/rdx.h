@@ -155,6 +155,11 @@ int rdx_enc_attention_f16(int device, const void* qkv, const int32_t* tok_first,
                           void* stream);
 int rdx_enc_add_layernorm_f16(int device, const void* a, const void* b, const void* gamma, const void* beta,
                               float eps, int64_t rows, int hidden, void* out, void* stream);
+/* rdx_enc_linear_small_f16: out[n_tokens][n_out] = act(x[n_tokens][n_in] w[n_out][n_in]^T + bias[n_out]) for at most 256 tokens (one
+ *   question, a question's sub-queries): the weight matrix is read once, fp32 accumulation; act 0 = none, 1 = erf GELU (the
+ *   checkpoint's). n_out a multiple of 16, n_in of 512. Larger token counts belong to the BLAS library. */
+int rdx_enc_linear_small_f16(int device, const void* x, const void* w, const void* bias, int n_tokens, int n_out,
+                             int n_in, int act, void* out, void* stream);
 
 /* `collection.query(query_embeddings=, n_results=k, where=)` (reference
  * src/rag/retriever.py:215-220,380-385; create_chromadb_index.py:405-408,435-439).

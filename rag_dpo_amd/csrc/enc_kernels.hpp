@@ -196,4 +196,94 @@ __global__ __launch_bounds__(256) void k_enc_add_ln(const _Float16* __restrict__
     }
 }
 
+// E3 k_enc_linear_small: out[T][N] = act(x[T][K] W[N][K]^T + bias) for SMALL token counts (T <= 256: one question, a question's
+//    sub-queries) — the shape where the BLAS library's GEMM takes 11 us whatever the size and the work is reading the weight matrix
+//    once (2 - 8 MB). One workgroup per 16 output features: its 4 waves split K, every wave streams its quarter of the 16 weight rows
+//    straight into MFMA A fragments (128 contiguous bytes per row and k-step of 64), the activations are the B operand (re-read from
+//    L2 by every workgroup: T*K*2 B, small), v_mfma_f32_16x16x32_f16 with the token on the lane; the four partial tiles meet in LDS,
+//    bias and the optional erf-GELU are applied in fp32, fp16 out. Roofline: HBM, N*K*2 B per launch. Pays up to ~32 tokens (one
+//    question): every workgroup re-reads all activations, so from 64 tokens on the BLAS library is as fast or faster and the host
+//    (rag_dpo_amd/embedding_provider.py SMALL_TOKENS) calls that instead; correct for any T <= 256.
+//    NTB = 16-token blocks (tokens beyond T repeat the last row and are not stored).
+//    NW = waves per workgroup that split K (4, or 16 for one or two token blocks: the whole slice of a wave — at most four k-steps of
+//    64 — is then requested before the first MFMA, so the kernel pays the memory latency once: 9.3 -> x us per projection of a question).
+template <int NTB, bool GELU, int NW>
+__global__ __launch_bounds__(NW * 64) void k_enc_linear_small(const _Float16* __restrict__ x, const _Float16* __restrict__ w,
+                                                              const _Float16* __restrict__ bias, int T, int N, int K,
+                                                              _Float16* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lin_smem[];
+    float* slab = reinterpret_cast<float*>(lin_smem);   // [NW waves][NTB * 4][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int kq = K / NW;                               // this wave's slice of K (a multiple of 64)
+    const _Float16* wp = w + (int64_t)(n0 + l15) * K + wave * kq + lq * 8;
+    const _Float16* xp[NTB];
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+        const int t = tb * 16 + l15;
+        xp[tb] = x + (int64_t)(t < T ? t : T - 1) * K + wave * kq + lq * 8;
+    }
+    f32x4 acc[NTB];
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) acc[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NW == 16) {
+        // kq = 64 .. 256: everything in flight at once
+        const int steps = kq >> 6;
+        half8 a[4][2] = {}, b[NTB][4][2] = {};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (s < steps) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    a[s][j] = *reinterpret_cast<const half8*>(wp + s * 64 + j * 32);
+#pragma unroll
+                    for (int tb = 0; tb < NTB; ++tb) b[tb][s][j] = *reinterpret_cast<const half8*>(xp[tb] + s * 64 + j * 32);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (s < steps) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int tb = 0; tb < NTB; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s][j], b[tb][s][j], acc[tb], 0, 0, 0);
+            }
+    } else {
+        for (int k0 = 0; k0 < kq; k0 += 128) {           // two k-steps of 64 per iteration: all their loads first
+            half8 a[4], b[NTB][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const half8*>(wp + k0 + j * 32);
+#pragma unroll
+            for (int tb = 0; tb < NTB; ++tb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[tb][j] = *reinterpret_cast<const half8*>(xp[tb] + k0 + j * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tb = 0; tb < NTB; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j], b[tb][j], acc[tb], 0, 0, 0);
+        }
+    }
+    // D[feature = lq * 4 + r][token = l15]: park the partial tile, sum the waves', finish
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(wave * NTB * 4 + tb * 4 + r) * 64 + lane] = acc[tb][r];
+    __syncthreads();
+    if (wave >= 4) return;
+    const int r = wave;                                   // thread -> (register r, lane): feature = (lane >> 4) * 4 + r, token = tb * 16 + (lane & 15)
+    const int f = n0 + lq * 4 + r;
+    const float bv = (float)bias[f];
+#pragma unroll
+    for (int tb = 0; tb < NTB; ++tb) {
+        const int t = tb * 16 + l15;
+        float v = bv;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) v += slab[(wv * NTB * 4 + tb * 4 + r) * 64 + lane];
+        if constexpr (GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        if (t < T) out[(int64_t)t * N + f] = (_Float16)v;
+    }
+}
+
 }  // namespace rdx

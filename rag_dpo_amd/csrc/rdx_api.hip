@@ -653,6 +653,44 @@ extern "C" int rdx_enc_attention_f16(int device, const void* qkv, const int32_t*
     return RDX_OK;
 }
 
+template <bool GELU>
+static void launch_linear_small(int ntb, dim3 grid, hipStream_t st, const _Float16* x, const _Float16* w, const _Float16* b, int T, int N, int K,
+                                _Float16* out) {
+    if (ntb <= 2 && K % 1024 == 0 && K <= 4096) {   // one question: 16 waves split K, a wave's whole slice in flight at once
+        const size_t lds = (size_t)16 * ntb * 1024;
+        if (ntb == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_enc_linear_small<1, GELU, 16>), grid, dim3(1024), lds, st, x, w, b, T, N, K, out);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_enc_linear_small<2, GELU, 16>), grid, dim3(1024), lds, st, x, w, b, T, N, K, out);
+        return;
+    }
+    const size_t lds = (size_t)ntb * 4096;   // 4 waves x ntb * 4 registers x 64 lanes x 4 B
+    switch (ntb) {
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_enc_linear_small<1, GELU, 4>), grid, dim3(256), lds, st, x, w, b, T, N, K, out); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_enc_linear_small<2, GELU, 4>), grid, dim3(256), lds, st, x, w, b, T, N, K, out); break;
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_enc_linear_small<4, GELU, 4>), grid, dim3(256), lds, st, x, w, b, T, N, K, out); break;
+        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_enc_linear_small<8, GELU, 4>), grid, dim3(256), lds, st, x, w, b, T, N, K, out); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_enc_linear_small<16, GELU, 4>), grid, dim3(256), lds, st, x, w, b, T, N, K, out); break;
+    }
+}
+
+extern "C" int rdx_enc_linear_small_f16(int device, const void* x, const void* w, const void* bias, int n_tokens, int n_out, int n_in,
+                                        int act, void* out, void* stream) {
+    if (n_tokens < 0 || n_tokens > 256) return fail(RDX_ERR_INVALID, "rdx_enc_linear_small_f16: at most 256 tokens (use the BLAS library beyond)");
+    if (n_out < 16 || n_out % 16 || n_in < 512 || n_in % 512) return fail(RDX_ERR_INVALID, "rdx_enc_linear_small_f16: n_out must be a multiple of 16, n_in of 512");
+    if (act != 0 && act != 1) return fail(RDX_ERR_INVALID, "rdx_enc_linear_small_f16: act is 0 (none) or 1 (erf GELU)");
+    if (n_tokens == 0) return RDX_OK;
+    if (!x || !w || !bias || !out) return fail(RDX_ERR_INVALID, "rdx_enc_linear_small_f16: null pointer");
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) return fail(RDX_ERR_INVALID, "rdx_enc_linear_small_f16: x, w and out must be 16-byte aligned");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_linear_small_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    int ntb = 1;
+    while (ntb * 16 < n_tokens) ntb *= 2;
+    const dim3 grid((unsigned)(n_out / 16));
+    if (act) launch_linear_small<true>(ntb, grid, (hipStream_t)stream, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, n_tokens, n_out, n_in, (_Float16*)out);
+    else launch_linear_small<false>(ntb, grid, (hipStream_t)stream, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, n_tokens, n_out, n_in, (_Float16*)out);
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
 extern "C" int rdx_enc_add_layernorm_f16(int device, const void* a, const void* b, const void* gamma, const void* beta, float eps,
                                          int64_t rows, int hidden, void* out, void* stream) {
     if (rows < 0 || hidden < 512 || hidden > 2048 || hidden % 512) return fail(RDX_ERR_INVALID, "rdx_enc_add_layernorm_f16: hidden must be 512, 1024, 1536 or 2048");

@@ -9,7 +9,8 @@ Reference behaviour mirrored (file:line in /root/reference/src/utils/embedding_p
 
 What differs underneath: the transformer forward runs over the checkpoint's `transformers.XLMRobertaModel` weights on the packed
 real tokens of a batch (`_PackedEncoder`: GEMMs and GELU are PyTorch-ROCm plumbing; on a GPU in fp16 the attention and the
-add + LayerNorm pairs are librdx kernels, `rdx_enc_attention_f16` / `rdx_enc_add_layernorm_f16`), CLS pooling as BGE-M3's dense
+add + LayerNorm pairs are librdx kernels, `rdx_enc_attention_f16` / `rdx_enc_add_layernorm_f16`, for a single question the
+projections too, `rdx_enc_linear_small_f16`; batches of up to 8 texts replay their forward as a HIP graph), CLS pooling as BGE-M3's dense
 head, and the L2-normalise is librdx K1 on the device (`rdx_l2_normalize`, the same arithmetic the index uses for corpus rows). Weights and tokenizer are loaded ONLY from a local directory
 (`model_name` itself, or `<cache_dir>/<model_name>` / HF-cache layout): this build never fetches by name
 (no network; HF_HUB_OFFLINE). `model_name="random-init:xlm-roberta-large"` builds the BGE-M3 architecture with
@@ -114,12 +115,15 @@ class _PackedEncoder:
         # questions: its work per token grows with the text). Anything else runs the torch operations below.
         self._lib = None
         self.fused = False
+        self.small_linear = False
         p0 = self.layers[0][0]
         if fused and p0.is_cuda and p0.dtype == torch.float16 and self.hidden // self.heads == 64 and self.hidden % 512 == 0 and self.hidden <= 2048:
             from . import _lib
             self._lib = _lib.load()          # raises RdxUnavailable: a GPU provider asked for its kernels and the library is missing
             self._last_error = _lib.last_error
             self.fused = True
+            inter0 = self.layers[0][4]
+            self.small_linear = self.hidden % 512 == 0 and inter0.weight.shape[0] % 512 == 0   # (rdx_enc_linear_small_f16: inputs a multiple of 512 wide)
 
     FUSED_MAX_TOKENS = 64
 
@@ -130,6 +134,19 @@ class _PackedEncoder:
                                                  torch.cuda.current_stream(a.device).cuda_stream)
         if rc:
             raise RuntimeError("rdx_enc_add_layernorm_f16: " + self._last_error())
+        return out
+
+    # up to here the projections are librdx's weight-streaming kernel (rdx_enc_linear_small_f16) instead of the BLAS library's GEMM. Measured
+    # (tools/enc_small_sweep.py, graph replay, XLM-R-large): one question (32 padded tokens) 1.71 -> 1.36 ms; at 64 tokens the two are
+    # equal (1.74), beyond the kernel loses (every 16-feature workgroup re-reads all activations: 128 tokens 2.12 against 1.78 ms)
+    SMALL_TOKENS = 32
+
+    def _linear(self, x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, gelu: bool = False) -> torch.Tensor:
+        out = torch.empty((x.shape[0], w.shape[0]), dtype=x.dtype, device=x.device)
+        rc = self._lib.rdx_enc_linear_small_f16(x.device.index or 0, x.data_ptr(), w.data_ptr(), b.data_ptr(), x.shape[0], w.shape[0], w.shape[1],
+                                                1 if gelu else 0, out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+        if rc:
+            raise RuntimeError("rdx_enc_linear_small_f16: " + self._last_error())
         return out
 
     def _attention(self, qkv: torch.Tensor, tok_first: torch.Tensor, tok_len: torch.Tensor, max_len: int) -> torch.Tensor:
@@ -162,12 +179,18 @@ class _PackedEncoder:
         F = torch.nn.functional
         x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
         last = len(self.layers) - 1
+        small = self.small_linear and x.shape[0] <= self.SMALL_TOKENS   # one question, a question's sub-queries: weight-streaming projections, GELU in the epilogue
         for li, (wqkv, bqkv, dense_o, ln1, inter, out, ln2) in enumerate(self.layers):
-            ctx = self._attention(F.linear(x, wqkv, bqkv), tok_first, tok_len, max_len)                           # [T][H], no padding anywhere
+            qkv = self._linear(x, wqkv, bqkv) if small else F.linear(x, wqkv, bqkv)
+            ctx = self._attention(qkv, tok_first, tok_len, max_len)                                               # [T][H], no padding anywhere
             if li == last:                                   # everything behind the last attention is row-wise: only the CLS rows are needed
                 ctx, x = ctx.index_select(0, first_d), x.index_select(0, first_d)
-            x = self._add_ln(dense_o(ctx), x, ln1)
-            x = self._add_ln(out(F.gelu(inter(x))), x, ln2)
+            if small:
+                x = self._add_ln(self._linear(ctx, dense_o.weight, dense_o.bias), x, ln1)
+                x = self._add_ln(self._linear(self._linear(x, inter.weight, inter.bias, gelu=True), out.weight, out.bias), x, ln2)
+            else:
+                x = self._add_ln(dense_o(ctx), x, ln1)
+                x = self._add_ln(out(F.gelu(inter(x))), x, ln2)
         return x.to(torch.float32)
 
     def _replay(self, key, host: dict, to_dev, max_len: int):

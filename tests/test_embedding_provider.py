@@ -297,6 +297,36 @@ def test_encoder_add_layernorm_kernel_vs_torch():
 
 
 @pytest.mark.gpu
+def test_encoder_small_linear_kernel_vs_fp32_reference():
+    """rdx_enc_linear_small_f16 (the projections of a forward over at most 256 tokens: the weight matrix streamed once, K split over a
+    workgroup's waves) against a plain torch fp32 reference of the same op, with and without the erf GELU: token counts 1..256 that are
+    no multiples of 16, the encoder's four shapes. Tolerance: fp16 output of fp32 accumulation over fp16 inputs (half an ulp relative
+    + the reference's own rounding): 2e-3 relative to the row's scale."""
+    import torch
+    from rag_dpo_amd import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(12)
+    for T, N, K in ((1, 1024, 1024), (20, 3072, 1024), (32, 4096, 1024), (45, 1024, 4096), (128, 1024, 1024), (200, 4096, 1024), (256, 1024, 4096), (7, 512, 512)):
+        x = (torch.randn((T, K), generator=g)).half().cuda()
+        w = (torch.randn((N, K), generator=g) * K ** -0.5).half().cuda()
+        b = (torch.randn((N,), generator=g) * 0.1).half().cuda()
+        for act in (0, 1):
+            out = torch.full((T, N), float("nan"), dtype=torch.float16, device="cuda")
+            rc = L.rdx_enc_linear_small_f16(0, x.data_ptr(), w.data_ptr(), b.data_ptr(), T, N, K, act, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, _lib.last_error()
+            want = x.float() @ w.float().T + b.float()
+            if act:
+                want = torch.nn.functional.gelu(want)
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            err = (out.float() - want).abs().max()
+            assert float(err) <= 2e-3 * max(1.0, float(want.abs().max())), (T, N, K, act, float(err))
+    assert L.rdx_enc_linear_small_f16(0, x.data_ptr(), w.data_ptr(), b.data_ptr(), 257, N, K, 0, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_linear_small_f16(0, x.data_ptr(), w.data_ptr(), b.data_ptr(), T, 24, K, 0, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_linear_small_f16(0, x.data_ptr(), w.data_ptr(), b.data_ptr(), T, N, 768, 0, out.data_ptr(), 0) != 0
+
+
+@pytest.mark.gpu
 def test_fused_encoder_kernels_equal_the_torch_operations():
     """the whole packed forward with librdx's attention and add + LayerNorm kernels against the same forward on torch operations
     (and against the module forward): same weights (seeded), fp16 on the GPU, 64-wide heads; texts of 1..60 tokens take the kernels,
