@@ -208,14 +208,19 @@ class _PackedEncoder:
             static = {n: torch.empty(tuple(t.shape), dtype=t.dtype, device=dev) for n, t in host.items()}
             for n, t in host.items():
                 to_dev(n, t, static[n])
-            side = torch.cuda.Stream(device=dev)                 # one eager run on a side stream first (library workspaces), as torch asks
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                self._fused_forward(*(static[n] for n in self._ORDER), max_len)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self._fused_forward(*(static[n] for n in self._ORDER), max_len)
+            try:
+                side = torch.cuda.Stream(device=dev)             # one eager run on a side stream first (library workspaces), as torch asks
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self._fused_forward(*(static[n] for n in self._ORDER), max_len)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self._fused_forward(*(static[n] for n in self._ORDER), max_len)
+            except Exception as e:                               # noqa: BLE001  (a capture that fails costs speed only: eager from now on)
+                logger.warning(f"encoder graph capture failed ({e!r}); the forward stays eager")
+                self.graphs = False
+                return None
             ent = (g, static, out)
         self._graph[key] = ent
         g, static, out = ent
