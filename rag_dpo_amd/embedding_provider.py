@@ -215,7 +215,10 @@ class _PackedEncoder:
                     self._fused_forward(*(static[n] for n in self._ORDER), max_len)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread-local capture mode: only THIS thread's calls are restricted while the capture runs — a search another
+                # thread has in flight on the same device (one shared provider and collection serve concurrent sessions, reference
+                # app.py:42-43) may allocate and synchronise as it likes
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     out = self._fused_forward(*(static[n] for n in self._ORDER), max_len)
             except Exception as e:                               # noqa: BLE001  (a capture that fails costs speed only: eager from now on)
                 logger.warning(f"encoder graph capture failed ({e!r}); the forward stays eager")

@@ -377,3 +377,46 @@ def test_fused_encoder_kernels_equal_the_torch_operations():
     assert list(fast._packed._graph) == [("small", 192, 32)]
 
 
+
+
+@pytest.mark.gpu
+def test_graph_capture_beside_a_search_on_another_thread(oracle):
+    """the provider captures its small-batch graphs in thread-local capture mode: searches running on another thread of the process
+    (one shared provider and collection serve concurrent sessions, reference app.py:42-43) allocate, launch and synchronise while a
+    capture is open — neither side may fail, and the answers stay the oracle's"""
+    import threading
+    import torch
+    from rag_dpo_amd import engine as eng, synth
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    corpus = synth.make_corpus(30_000, 256)
+    q = synth.make_queries(8, 256, corpus)
+    ix = eng.HipIndex(256)
+    ix.add(corpus)
+    es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, 10, None)
+    stop, errors, n_search = threading.Event(), [], [0]
+
+    def searcher():
+        try:
+            while not stop.is_set():
+                s, r, c = ix.search(q, 10)
+                assert (r == er).all()
+                n_search[0] += 1
+        except Exception as e:                       # noqa: BLE001
+            errors.append(e)
+
+    th = threading.Thread(target=searcher)
+    th.start()
+    try:
+        p = EmbeddingProvider(model_name="random-init:mid", device="cuda:0", dtype=torch.float16, batch_size=64).load()
+        words = [f"w{i}" for i in range(40)]
+        for n in range(1, 33):                        # many shapes: each is captured the second time it is seen
+            texts = [" ".join(words[:n])] * (1 + n % 3)
+            for _ in range(3):
+                p.embed_device(texts)
+        torch.cuda.synchronize()
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    assert p._packed.graphs == "auto" and len(p._packed._graph) >= 3 and n_search[0] > 0
+    ix.close()
