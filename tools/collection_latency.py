@@ -39,3 +39,28 @@ print("query 4 x top-50 in one call    : %.3f ms" % timeit(lambda: col.query(que
 print("query 1 x top-50, ids+distances : %.3f ms" % timeit(lambda: col.query(query_embeddings=one, n_results=50, include=["distances"])))
 qn = np.ascontiguousarray(q[:1])
 print("engine.search 1 x top-50 (numpy): %.3f ms" % timeit(lambda: col._engine.search(qn, 50)))
+
+if "--online" in sys.argv:
+    # the reference's whole online step for one question: embed_query, then collection.query (src/rag/retriever.py:150-154, 215-220),
+    # and this repo's retriever form: the question's <= 4 sub-queries embedded together and searched in one call
+    import torch
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    texts = synth.query_texts(16)
+    for name, packed in (("module forward", False), ("librdx kernels + graph replay (default)", True)):
+        p = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device="cuda:0", dtype=torch.float16, batch_size=64)
+        p.packed_forward = packed
+        p.load()
+        it = [0]
+        def one_q():
+            it[0] += 1
+            v = p.embed([texts[it[0] % 8]])
+            return col.query(query_embeddings=v, n_results=50, where=where, include=inc)
+        def four_q():
+            it[0] += 1
+            a = (it[0] % 3) * 4
+            v = p.embed(texts[a:a + 4])
+            return col.query(query_embeddings=v, n_results=50, where=where, include=inc)
+        for _ in range(30):
+            one_q(); four_q()
+        print("embed([question]) + query, where $in, top-50      [%s]: %.3f ms" % (name, timeit(one_q, 100)))
+        print("embed(4 sub-queries) + query in one call, top-50  [%s]: %.3f ms" % (name, timeit(four_q, 100)))
