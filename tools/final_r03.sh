@@ -13,7 +13,9 @@ timeout -k 10 400 python3 bench.py --workload c5 --no-cpu > $O/c5.json 2> $O/c5.
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --enc-torch-ops > $O/c5_torch_ops.json 2> /dev/null || echo "bench c5 torch ops failed"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --enc-module-forward > $O/c5_module_forward.json 2> /dev/null || echo "bench c5 module failed"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu > $O/c5_again.json 2> /dev/null || echo "bench c5 again failed"
-timeout -k 10 300 python3 tools/enc_ab.py 2>&1 | grep -v amdgpu.ids > $O/c5_encode_gpu_time.txt || echo "enc_ab failed"
+timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --enc-graphs > $O/c5_graph_replay.json 2> /dev/null || echo "bench c5 graphs failed"
+ENC_AB_GRAPH=1 timeout -k 10 300 python3 tools/enc_ab.py 2>&1 | grep -v amdgpu.ids > $O/c5_encode_gpu_time.txt || echo "enc_ab failed"
+timeout -k 10 300 python3 tools/enc_single.py 2>&1 | grep -v amdgpu.ids > $O/c1_encode_one_question_latency.txt || echo "enc_single failed"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu --no-encode > $O/c5_noenc.json 2> /dev/null || echo "bench c5 noenc failed"
 timeout -k 10 400 python3 bench.py --workload c4 --no-cpu --set spec_tau=0 > $O/c4_nospec.json 2> /dev/null || echo "bench c4 nospec failed"
 timeout -k 10 400 python3 bench.py --workload c3 --no-cpu --set spec_tau=0 > $O/c3_nospec.json 2> /dev/null || echo "bench c3 nospec failed"
@@ -73,7 +75,8 @@ timeout -k 10 400 bash tools/pmc.sh r03sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_IN
 rm -rf $R/gpurun_out/pmc_r03sq $R/gpurun_out/prof_r03/*/*/*kernel_trace.csv
 timeout -k 10 300 python3 bench.py --workload c4 --no-cpu --rows 1250000 --steps 30 --warmup 5 > $O/c4_one_eighth.json 2> /dev/null || echo "one-eighth failed"
 timeout -k 10 300 python3 bench.py --workload c4 --no-cpu --rows 1250000 --steps 30 --warmup 5 --force-dist > $O/c4_one_eighth_rccl_world1.json 2> /dev/null || echo "one-eighth rccl failed"
-python3 tools/collection_latency.py 2>/dev/null | grep -v amdgpu > $O/collection_latency.txt
+python3 tools/collection_latency.py --online 2>/dev/null | grep -v amdgpu > $O/collection_latency.txt
+bash tools/r03_encpmc.sh > /dev/null 2>&1 && cp $R/gpurun_out/r03_encpmc/c5_encode_traffic_pmc.txt $O/ || echo "enc pmc failed"
 RDX_BENCH_REHEARSAL=1 timeout -k 10 300 python3 bench.py --gpus 2 --rows 600000 --steps 3 --warmup 1 --check-merged > $O/rehearse2_selflaunch.json 2> $O/rehearse2.err; echo "self-launch rehearsal rc=$?"
 RDX_BENCH_REHEARSAL=1 timeout -k 10 300 python3 bench.py --gpus 3 --workload c3 --rows 300000 --steps 3 --warmup 1 --set cand_cap=8 > $O/rehearse3_overflow.json 2> $O/rehearse3.err; echo "overflow rehearsal rc=$?"
 timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.txt
