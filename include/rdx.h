@@ -45,7 +45,7 @@ extern "C" {
 #define RDX_HOST 0
 #define RDX_DEVICE 1
 
-#define RDX_ABI_VERSION 2 /* 2: flags word in the packed partial, rdx_signal, rdx_search_async(out_flags) */
+#define RDX_ABI_VERSION 3 /* 2: flags word in the packed partial, rdx_signal, rdx_search_async(out_flags); 3: the single-question encoder stages */
 
 typedef struct rdx_index rdx_index; /* opaque: one corpus shard resident in one GPU's HBM */
 
@@ -53,6 +53,13 @@ typedef struct rdx_index rdx_index; /* opaque: one corpus shard resident in one 
 int rdx_version(void);
 const char* rdx_last_error(void);
 int rdx_device_count(int* n);
+/* How the host waits for a search (rdx_search, rdx_search_wait, rdx_signal_wait), process-wide. Default (400, 0): spin on the
+ * search's pinned mailbox word for spin_us, then poll it with sched_yield() between looks — lowest latency, one host core busy per
+ * waiting thread for the length of the search. sleep_us > 0: after the spin, sleep that long between looks (a server whose
+ * sessions share the cores — the reference serves concurrent Streamlit sessions from one process, app.py:42-43 — wants e.g.
+ * (50, 100): small searches still end inside the spin, a 15 ms scan costs ~1 % of a core and is noticed <= 100 us late).
+ * Environment RDX_WAIT_SPIN_US / RDX_WAIT_SLEEP_US set the initial values. Speed only. */
+int rdx_set_wait_policy(int spin_us, int sleep_us);
 
 /* Index lifecycle — replaces chromadb `create_collection(..., {"hnsw:space": "cosine"})` /
  * `get_collection` (reference create_chromadb_index.py:100-106,112; app.py:58-59). */
@@ -161,6 +168,39 @@ int rdx_enc_add_layernorm_f16(int device, const void* a, const void* b, const vo
 int rdx_enc_linear_small_f16(int device, const void* x, const void* w, const void* bias, int n_tokens, int n_out,
                              int n_in, int act, void* out, void* stream);
 
+/* The forward of ONE question — `EmbeddingProvider.embed_query` / `embed([q])` in front of every `collection.query`
+ * (reference src/utils/embedding_provider.py:118-157, called at src/rag/retriever.py:150-154, 212, 377) — as five launches per
+ * transformer layer for at most 32 packed tokens (a question, or a question's short sub-queries). All pointers fp16 device
+ * memory, 16-byte aligned, enqueued on `stream`, nothing synchronised. rag_dpo_amd/embedding_provider.py chains them and replays
+ * the chain as one HIP graph.
+ *
+ * rdx_enc_embed_f16: out[t] = (word[tok[t]] + pos[pos_id[t]]) + type0 — the embedding sum in the module's order of fp16 adds; its
+ *   LayerNorm is the first rdx_enc_stage_f16's prologue.
+ * rdx_enc_stage_f16: out[n_tokens][n_out] = epi(in[n_tokens][n_in] w[n_out][n_in]^T + bias), fp32 accumulation, the weight matrix
+ *   read once by n_out / features_per_workgroup workgroups (16, or 8 / 4 so that a 1024-feature projection still covers 128 / 256
+ *   CUs; 0 = 16). n_in 512, 1024, 2048 or 4096.
+ *     ln_gamma != NULL: `x` holds pre-LayerNorm sums s and in = LayerNorm(s) * ln_gamma + ln_beta (fp32 statistics, biased
+ *       variance), recomputed by every workgroup; if y_out != NULL that LayerNorm output [n_tokens][n_in] is stored as well (the
+ *       residual of the block's second half). n_in 512 or 1024, 16 features per workgroup, epilogue 0 or 1.
+ *     ln_gamma == NULL: in = x, or rows x_rows[t] of x (and of `res`) when x_rows != NULL (the last layer: CLS rows only).
+ *     epilogue 0: + bias; 1: erf GELU(+ bias); 2: res + (fp16)(+ bias) — the block's residual sum, rounded as the module's
+ *       fp16 add rounds it; `out` then holds the next LayerNorm's input.
+ *     prefetch / prefetch_bytes: the NEXT stage's weight matrix (or NULL / 0): waves that are done touch it so that it waits in
+ *       the Infinity Cache (speed only).
+ * rdx_enc_attention_small_f16: rdx_enc_attention_f16 for at most 32 tokens on MFMA, one workgroup per head: token t attends to
+ *   the tokens u with tok_first[u] == tok_first[t].
+ * rdx_enc_layernorm_rows_f16: out[r] (fp32) = (fp16) LayerNorm(s[r]) — the last LayerNorm, on the CLS rows. */
+int rdx_enc_embed_f16(int device, const int64_t* tok, const int64_t* pos_id, const void* word, const void* pos,
+                      const void* type0, int n_tokens, int hidden, void* out, void* stream);
+int rdx_enc_stage_f16(int device, const void* x, const int64_t* x_rows, const void* ln_gamma, const void* ln_beta,
+                      float ln_eps, void* y_out, const void* w, const void* bias, const void* res, int n_tokens,
+                      int n_out, int n_in, int epilogue, int features_per_workgroup, const void* prefetch,
+                      int64_t prefetch_bytes, void* out, void* stream);
+int rdx_enc_attention_small_f16(int device, const void* qkv, const int32_t* tok_first, int n_tokens, int heads,
+                                int head_dim, float scale, void* ctx, void* stream);
+int rdx_enc_layernorm_rows_f16(int device, const void* s, const void* gamma, const void* beta, float eps, int rows,
+                               int hidden, float* out, void* stream);
+
 /* `collection.query(query_embeddings=, n_results=k, where=)` (reference
  * src/rag/retriever.py:215-220,380-385; create_chromadb_index.py:405-408,435-439).
  *   queries     [nq][dim] raw fp32 (normalised on the device like corpus rows)
@@ -225,7 +265,8 @@ int rdx_signal_wait(rdx_signal* s, void* stream, int32_t* value);
 /* Same merge, reading the partials straight out of the all-gather receive buffer (device memory):
  * part p starts part_stride bytes (multiple of 16) after part p-1 and is one rank's packed contribution
  * rows int64[nq][k] | scores f32[nq][k] | counts int32[nq] | flags int32[RDX_PACKED_FLAGS]
- * (= nq*k*12 + nq*4 + 16 bytes). Outputs are device pointers; k >= 1. sig: NULL, or the signal through which the first block
+ * (= nq*k*12 + nq*4 + 16 bytes). Outputs are device pointers; k >= 1; n_parts * k <= 4096 (unlike rdx_merge_topk the packed form
+ * does not fold: rag_dpo_amd/sharded.py checks world * k before it enqueues anything, so no rank fails behind a collective). sig: NULL, or the signal through which the first block
  * publishes the OR of the parts' flags[0] as soon as it has read them (the decision "some partial was incomplete: exchange
  * again" does not wait for the merge itself). */
 int rdx_merge_topk_packed(int device, const void* packed, int64_t part_stride, int n_parts, int64_t nq,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RDX_LIB_PATH") or os.path.join(_HERE, "librdx.so")
 
 RDX_OK, RDX_ERR_INVALID, RDX_ERR_HIP, RDX_ERR_NOMEM, RDX_ERR_STATE = 0, 1, 2, 3, 4
 RDX_HOST, RDX_DEVICE = 0, 1
-ABI_VERSION = 2          # include/rdx.h RDX_ABI_VERSION
+ABI_VERSION = 3          # include/rdx.h RDX_ABI_VERSION
 PACKED_FLAGS = 4         # include/rdx.h RDX_PACKED_FLAGS: int32 words behind the counts of a packed partial
 
 
@@ -53,6 +53,7 @@ SYMBOLS = {
     "rdx_version": (_i, []),
     "rdx_last_error": (ctypes.c_char_p, []),
     "rdx_device_count": (_i, [ctypes.POINTER(_i)]),
+    "rdx_set_wait_policy": (_i, [_i, _i]),
     "rdx_index_create": (_i, [_i, _i, ctypes.POINTER(_vp)]),
     "rdx_index_destroy": (_i, [_vp]),
     "rdx_index_dim": (_i, [_vp, ctypes.POINTER(_i)]),
@@ -71,6 +72,10 @@ SYMBOLS = {
     "rdx_enc_attention_f16": (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, ctypes.c_float, _i, _vp, _vp]),
     "rdx_enc_linear_small_f16": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rdx_enc_add_layernorm_f16": (_i, [_i, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i, _vp, _vp]),
+    "rdx_enc_embed_f16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "rdx_enc_stage_f16": (_i, [_i, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp]),
+    "rdx_enc_attention_small_f16": (_i, [_i, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp, _vp]),
+    "rdx_enc_layernorm_rows_f16": (_i, [_i, _vp, _vp, _vp, ctypes.c_float, _i, _i, _vp, _vp]),
     "rdx_search": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "rdx_mask_create": (_i, [_vp, _vp, _i, ctypes.POINTER(_vp)]),
     "rdx_mask_destroy": (_i, [_vp]),

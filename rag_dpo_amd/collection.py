@@ -658,11 +658,23 @@ class Collection:
                 _fsync_dir(path)                      # the new generation's files exist before the header can name them
                 self._write_header(path, n, fmt=3, gen=new_gen)   # commit point: the header names generation g+1
             except BaseException:
-                for fn in (nm["emb"], nm["rec"], "collection.json.tmp"):   # partial files of the generation that never committed
-                    try:
-                        os.remove(os.path.join(path, fn))
-                    except OSError:
-                        pass
+                # os.replace(collection.json) IS the commit point: if the header on disk names generation g+1 (the replace
+                # happened and something after it raised — the directory fsync, an interrupt), the new files are the store and
+                # must stay; the object follows the header, so that later writes go to the journal the header names.
+                committed = False
+                try:
+                    with open(os.path.join(path, "collection.json"), encoding="utf-8") as f:
+                        committed = int(json.load(f).get("gen", -1)) == new_gen
+                except (OSError, ValueError):
+                    pass
+                if committed:
+                    self._snap_format, self._gen, self._snap_rows = 3, new_gen, n
+                else:
+                    for fn in (nm["emb"], nm["rec"], "collection.json.tmp"):   # partial files of the generation that never committed
+                        try:
+                            os.remove(os.path.join(path, fn))
+                        except OSError:
+                            pass
                 raise
             self._snap_format, self._gen, self._snap_rows = 3, new_gen, n
             for fn in old.values():

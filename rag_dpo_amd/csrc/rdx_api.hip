@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +22,7 @@
 #include <immintrin.h>
 
 #include "enc_kernels.hpp"
+#include "enc_small.hpp"
 #include "k_rows.hpp"
 #include "refine_kernel.hpp"
 #include "scan_kernel.hpp"
@@ -713,6 +715,163 @@ extern "C" int rdx_enc_add_layernorm_f16(int device, const void* a, const void* 
     return RDX_OK;
 }
 
+// ---- the single-question forward: E4..E7 (enc_small.hpp) ----------------------------------------------------------------------
+// kernels with more than 64 KiB of dynamic LDS need the limit raised once per kernel and device
+static std::mutex g_enc_attr_mu;
+static std::unordered_map<const void*, size_t>* const g_enc_attr = new std::unordered_map<const void*, size_t>[64];
+static int enc_dynamic_lds(int device, const void* func, size_t bytes) {
+    if (bytes <= 65536) return RDX_OK;
+    std::lock_guard<std::mutex> lk(g_enc_attr_mu);
+    size_t& have = g_enc_attr[device][func];
+    if (have < bytes) {
+        HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return RDX_OK;
+}
+
+template <int NTB, int KS, int FPB, bool LNPRO, int EPI>
+static int launch_enc_stage(int device, const EncStage& a, hipStream_t st) {
+    const size_t lds = (size_t)NTB * 16384 + (LNPRO ? (size_t)NTB * 16 * KS * 512 * 2 : 0) + 12288;
+    auto* fn = k_enc_stage<NTB, KS, FPB, LNPRO, EPI>;
+    RDX_TRY(enc_dynamic_lds(device, (const void*)fn, lds));
+    hipLaunchKernelGGL(fn, dim3((unsigned)(a.N / FPB)), dim3(1024), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
+template <int NTB, int KS>
+static int dispatch_enc_stage(int device, const EncStage& a, bool lnpro, int epi, int fpb, hipStream_t st) {
+    if (lnpro) {
+        if constexpr (KS <= 2) {
+            if (epi == ENC_EPI_BIAS) return launch_enc_stage<NTB, KS, 16, true, ENC_EPI_BIAS>(device, a, st);
+            if (epi == ENC_EPI_GELU) return launch_enc_stage<NTB, KS, 16, true, ENC_EPI_GELU>(device, a, st);
+        }
+        return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: the LayerNorm prologue takes n_in 512 or 1024 and epilogue 0 or 1");
+    }
+#define RDX_ENC_PLAIN(F)                                                                                                   \
+    if (fpb == F) {                                                                                                        \
+        if (epi == ENC_EPI_BIAS) return launch_enc_stage<NTB, KS, F, false, ENC_EPI_BIAS>(device, a, st);                  \
+        if (epi == ENC_EPI_GELU) return launch_enc_stage<NTB, KS, F, false, ENC_EPI_GELU>(device, a, st);                  \
+        return launch_enc_stage<NTB, KS, F, false, ENC_EPI_RESIDUAL>(device, a, st);                                        \
+    }
+    RDX_ENC_PLAIN(16)
+    RDX_ENC_PLAIN(8)
+    RDX_ENC_PLAIN(4)
+#undef RDX_ENC_PLAIN
+    return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: features_per_workgroup is 16, 8 or 4");
+}
+
+extern "C" int rdx_enc_stage_f16(int device, const void* x, const int64_t* x_rows, const void* ln_gamma, const void* ln_beta, float ln_eps,
+                                 void* y_out, const void* w, const void* bias, const void* res, int n_tokens, int n_out, int n_in,
+                                 int epilogue, int features_per_workgroup, const void* prefetch, int64_t prefetch_bytes, void* out,
+                                 void* stream) {
+    if (n_tokens < 0 || n_tokens > 32) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: at most 32 tokens");
+    if (n_in != 512 && n_in != 1024 && n_in != 2048 && n_in != 4096) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: n_in must be 512, 1024, 2048 or 4096");
+    if (epilogue < 0 || epilogue > 2) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: epilogue is 0 (bias), 1 (bias + erf GELU) or 2 (bias + residual)");
+    int fpb = features_per_workgroup ? features_per_workgroup : 16;
+    if (n_out < fpb || n_out % fpb) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: n_out must be a multiple of features_per_workgroup");
+    const bool lnpro = ln_gamma != nullptr;
+    if (lnpro && (!ln_beta || x_rows)) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: the LayerNorm prologue needs gamma and beta and takes no row list");
+    if (lnpro && fpb != 16) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: the LayerNorm prologue runs with 16 features per workgroup");
+    if (epilogue == 2 && !res) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: epilogue 2 needs the residual");
+    if (prefetch_bytes < 0 || (prefetch_bytes && !prefetch)) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: bad prefetch range");
+    if (n_tokens == 0) return RDX_OK;
+    if (!x || !w || !bias || !out) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: null pointer");
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)y_out | (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)prefetch) & 15)
+        return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: pointers must be 16-byte aligned");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    EncStage a;
+    a.x = (const _Float16*)x;
+    a.x_rows = x_rows;
+    a.gamma = (const _Float16*)ln_gamma;
+    a.beta = (const _Float16*)ln_beta;
+    a.eps = ln_eps;
+    a.y_out = (_Float16*)y_out;
+    a.w = (const _Float16*)w;
+    a.bias = (const _Float16*)bias;
+    a.res = (const _Float16*)res;
+    a.out = (_Float16*)out;
+    a.T = n_tokens;
+    a.N = n_out;
+    a.pf = (const char*)prefetch;
+    a.pf_bytes = (uint32_t)std::min<int64_t>(prefetch_bytes, (int64_t)1 << 30) & ~1023u;
+    hipStream_t st = (hipStream_t)stream;
+    const int ks = n_in / 512;
+#define RDX_ENC_KS(NTB)                                                                \
+    switch (ks) {                                                                      \
+        case 1: return dispatch_enc_stage<NTB, 1>(device, a, lnpro, epilogue, fpb, st); \
+        case 2: return dispatch_enc_stage<NTB, 2>(device, a, lnpro, epilogue, fpb, st); \
+        case 4: return dispatch_enc_stage<NTB, 4>(device, a, lnpro, epilogue, fpb, st); \
+        default: return dispatch_enc_stage<NTB, 8>(device, a, lnpro, epilogue, fpb, st); \
+    }
+    if (n_tokens <= 16) { RDX_ENC_KS(1) }
+    RDX_ENC_KS(2)
+#undef RDX_ENC_KS
+}
+
+extern "C" int rdx_enc_attention_small_f16(int device, const void* qkv, const int32_t* tok_first, int n_tokens, int heads, int head_dim,
+                                           float scale, void* ctx, void* stream) {
+    if (n_tokens < 0 || n_tokens > 32) return fail(RDX_ERR_INVALID, "rdx_enc_attention_small_f16: at most 32 tokens");
+    if (heads < 1 || heads > 65535 || head_dim != ENC_HEAD_DIM) return fail(RDX_ERR_INVALID, "rdx_enc_attention_small_f16: head_dim must be 64");
+    if (n_tokens == 0) return RDX_OK;
+    if (!qkv || !tok_first || !ctx) return fail(RDX_ERR_INVALID, "rdx_enc_attention_small_f16: null pointer");
+    if (((uintptr_t)qkv | (uintptr_t)ctx) & 15) return fail(RDX_ERR_INVALID, "rdx_enc_attention_small_f16: qkv and ctx must be 16-byte aligned");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_attention_small_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    const float sl2 = scale * 1.4426950408889634f;
+    if (n_tokens <= 16)
+        hipLaunchKernelGGL(k_enc_attn_small<1>, dim3((unsigned)heads), dim3(64), 0, (hipStream_t)stream, (const _Float16*)qkv, tok_first, n_tokens, heads, sl2, (_Float16*)ctx);
+    else
+        hipLaunchKernelGGL(k_enc_attn_small<2>, dim3((unsigned)heads), dim3(128), 0, (hipStream_t)stream, (const _Float16*)qkv, tok_first, n_tokens, heads, sl2, (_Float16*)ctx);
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
+extern "C" int rdx_enc_embed_f16(int device, const int64_t* tok, const int64_t* pos_id, const void* word, const void* pos, const void* type0,
+                                 int n_tokens, int hidden, void* out, void* stream) {
+    if (n_tokens < 0 || hidden < 512 || hidden > 2048 || hidden % 512) return fail(RDX_ERR_INVALID, "rdx_enc_embed_f16: hidden must be 512, 1024, 1536 or 2048");
+    if (n_tokens == 0) return RDX_OK;
+    if (!tok || !pos_id || !word || !pos || !type0 || !out) return fail(RDX_ERR_INVALID, "rdx_enc_embed_f16: null pointer");
+    if (((uintptr_t)word | (uintptr_t)pos | (uintptr_t)type0 | (uintptr_t)out) & 15) return fail(RDX_ERR_INVALID, "rdx_enc_embed_f16: pointers must be 16-byte aligned");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_embed_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    const dim3 grid((unsigned)((n_tokens + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16 *pw = (const _Float16*)word, *pp = (const _Float16*)pos, *pt = (const _Float16*)type0;
+    switch (hidden / 512) {
+        case 1: hipLaunchKernelGGL(k_enc_embed<1>, grid, block, 0, st, tok, pos_id, pw, pp, pt, n_tokens, (_Float16*)out); break;
+        case 2: hipLaunchKernelGGL(k_enc_embed<2>, grid, block, 0, st, tok, pos_id, pw, pp, pt, n_tokens, (_Float16*)out); break;
+        case 3: hipLaunchKernelGGL(k_enc_embed<3>, grid, block, 0, st, tok, pos_id, pw, pp, pt, n_tokens, (_Float16*)out); break;
+        default: hipLaunchKernelGGL(k_enc_embed<4>, grid, block, 0, st, tok, pos_id, pw, pp, pt, n_tokens, (_Float16*)out); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
+extern "C" int rdx_enc_layernorm_rows_f16(int device, const void* s, const void* gamma, const void* beta, float eps, int rows, int hidden,
+                                          float* out, void* stream) {
+    if (rows < 0 || hidden < 512 || hidden > 2048 || hidden % 512) return fail(RDX_ERR_INVALID, "rdx_enc_layernorm_rows_f16: hidden must be 512, 1024, 1536 or 2048");
+    if (rows == 0) return RDX_OK;
+    if (!s || !gamma || !beta || !out) return fail(RDX_ERR_INVALID, "rdx_enc_layernorm_rows_f16: null pointer");
+    if (((uintptr_t)s | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) return fail(RDX_ERR_INVALID, "rdx_enc_layernorm_rows_f16: pointers must be 16-byte aligned");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_layernorm_rows_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16 *ps = (const _Float16*)s, *pg = (const _Float16*)gamma, *pb = (const _Float16*)beta;
+    switch (hidden / 512) {
+        case 1: hipLaunchKernelGGL(k_enc_ln_rows<1>, grid, block, 0, st, ps, pg, pb, eps, rows, out); break;
+        case 2: hipLaunchKernelGGL(k_enc_ln_rows<2>, grid, block, 0, st, ps, pg, pb, eps, rows, out); break;
+        case 3: hipLaunchKernelGGL(k_enc_ln_rows<3>, grid, block, 0, st, ps, pg, pb, eps, rows, out); break;
+        default: hipLaunchKernelGGL(k_enc_ln_rows<4>, grid, block, 0, st, ps, pg, pb, eps, rows, out); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
+
 extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space, void* stream) {
     if (n < 0 || (n > 0 && (!in || !out))) return fail(RDX_ERR_INVALID, "rdx_l2_normalize: bad argument");
     RDX_TRY(check_dim(dim));
@@ -887,28 +1046,47 @@ static int ensure_pin_out(rdx_index* h, size_t bytes) {
 // between looks (a 0.6 - 25 ms search is noticed within a microsecond; measured with 20 us sleeps instead: +30 us on a 0.56 ms search,
 // +170 us on a 2.2 ms one), after 200 ms with 50 us sleeps. The stream is only QUERIED, every 50 ms, to turn a failed or vanished
 // launch into an error instead of an endless wait. 0 = arrived, 1 = the stream ran dry without the word, < 0 = error code.
-static int g_wait_spin_us = [] {   // developer knob: how long the hot spin lasts before the polite poll takes over
+// Wait policy (rdx_set_wait_policy; environment RDX_WAIT_SPIN_US / RDX_WAIT_SLEEP_US at load): the default burns a host core for the
+// length of a search — right for a benchmark or one rank per GPU, wrong for a server whose sessions share the cores (the reference
+// serves concurrent Streamlit sessions from one process, app.py:42-43). sleep_us > 0: after the hot spin the waiter SLEEPS that long
+// between looks (a 15 ms scan then costs the core ~1 % instead of 100 %; the result is noticed up to sleep_us later).
+static std::atomic<int> g_wait_spin_us{[] {
     const char* e = std::getenv("RDX_WAIT_SPIN_US");
     return e ? std::atoi(e) : 400;
-}();
+}()};
+static std::atomic<int> g_wait_sleep_us{[] {
+    const char* e = std::getenv("RDX_WAIT_SLEEP_US");
+    return e ? std::max(0, std::atoi(e)) : 0;
+}()};
+extern "C" int rdx_set_wait_policy(int spin_us, int sleep_us) {
+    if (spin_us < 0 || sleep_us < 0 || sleep_us > 1000000) return fail(RDX_ERR_INVALID, "rdx_set_wait_policy: spin_us >= 0, 0 <= sleep_us <= 1000000");
+    g_wait_spin_us.store(spin_us);
+    g_wait_sleep_us.store(sleep_us);
+    return RDX_OK;
+}
 template <class F>
 static int wait_word(F ready, hipStream_t st) {
     const auto t0 = std::chrono::steady_clock::now();
+    const int spin_us = g_wait_spin_us.load(std::memory_order_relaxed), sleep_us = g_wait_sleep_us.load(std::memory_order_relaxed);
     for (unsigned spins = 1;; ++spins) {
         if (ready()) return 0;
+        if (spin_us == 0) break;
         _mm_pause();
-        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(g_wait_spin_us)) break;
+        if ((spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
     }
     auto next_query = t0 + std::chrono::milliseconds(50);
     const auto t_sleep = t0 + std::chrono::milliseconds(200);
     for (unsigned n = 1;; ++n) {
         if (ready()) return 0;
-        if ((n & 15u) != 0) {
+        if (sleep_us > 0) {
+            std::this_thread::sleep_for(std::chrono::microseconds(sleep_us));
+            if (ready()) return 0;
+        } else if ((n & 15u) != 0) {
             sched_yield();
             continue;
         }
         const auto now = std::chrono::steady_clock::now();
-        if (now >= t_sleep) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (sleep_us == 0 && now >= t_sleep) std::this_thread::sleep_for(std::chrono::microseconds(50));
         if (now >= next_query) {
             const hipError_t e = hipStreamQuery(st);
             if (e == hipSuccess) return ready() ? 0 : 1;   // everything enqueued has run: the word must be there

@@ -116,6 +116,7 @@ class _PackedEncoder:
         self._lib = None
         self.fused = False
         self.small_linear = False
+        self.small_stage = False
         p0 = self.layers[0][0]
         if fused and p0.is_cuda and p0.dtype == torch.float16 and self.hidden // self.heads == 64 and self.hidden % 512 == 0 and self.hidden <= 2048:
             from . import _lib
@@ -124,6 +125,11 @@ class _PackedEncoder:
             self.fused = True
             inter0 = self.layers[0][4]
             self.small_linear = self.hidden % 512 == 0 and inter0.weight.shape[0] % 512 == 0   # (rdx_enc_linear_small_f16: inputs a multiple of 512 wide)
+            # the five-launches-per-layer forward of one question (rdx_enc_stage_f16 & co., csrc/enc_small.hpp)
+            self.small_stage = self.hidden in (512, 1024) and inter0.weight.shape[0] in (512, 1024, 2048, 4096)
+            self.stage_fpb_o = int(os.environ.get("RDX_ENC_FPB_O", self.STAGE_FPB_O))
+            self.stage_fpb_f2 = int(os.environ.get("RDX_ENC_FPB_F2", self.STAGE_FPB_F2))
+            self.stage_prefetch = os.environ.get("RDX_ENC_PREFETCH", "1" if self.STAGE_PREFETCH else "0") != "0"
 
     FUSED_MAX_TOKENS = 64
 
@@ -174,8 +180,62 @@ class _PackedEncoder:
     SMALL_TEXTS = 8
     SMALL_TOKEN_GRANULE = 32
 
+    # One question (at most STAGE_TOKENS packed tokens, padded to 16 or 32): five launches per layer, csrc/enc_small.hpp. The output
+    # projection and FFN-down have 1024 features: with 16 per workgroup they would occupy 64 CUs, so their workgroups take 8 / 4 rows of
+    # the MFMA tile (developer knobs RDX_ENC_FPB_O / RDX_ENC_FPB_F2 / RDX_ENC_PREFETCH; measured values in DESIGN.md §10).
+    STAGE_TOKENS = 32
+    STAGE_FPB_O = 8
+    STAGE_FPB_F2 = 4
+    STAGE_PREFETCH = False   # measured (profiles/r04/enc_small_sweep.txt): touching the next stage's weights from the idle waves makes every kernel wait for those loads: +0.08 ms per question
+
+    def _stage(self, x, w, b, T, ln=None, y_out=None, res=None, rows=None, epi=0, fpb=0, pf=None):
+        N, K = int(w.shape[0]), int(w.shape[1])
+        out = torch.empty((T, N), dtype=torch.float16, device=w.device)
+        pfb = pf.numel() * 2 if (pf is not None and self.stage_prefetch) else 0
+        rc = self._lib.rdx_enc_stage_f16(w.device.index or 0, x.data_ptr(), rows.data_ptr() if rows is not None else None,
+                                         ln.weight.data_ptr() if ln is not None else None, ln.bias.data_ptr() if ln is not None else None,
+                                         float(ln.eps) if ln is not None else 0.0, y_out.data_ptr() if y_out is not None else None,
+                                         w.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, T, N, K, epi, fpb,
+                                         pf.data_ptr() if pfb else None, pfb, out.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream)
+        if rc:
+            raise RuntimeError("rdx_enc_stage_f16: " + self._last_error())
+        return out
+
+    def _small_forward(self, tok, pos, first_d, tok_first) -> torch.Tensor:
+        """[T <= 32] ids / positions -> fp32 [len(first_d)][hidden] CLS rows; librdx kernels only (no torch operation on the stream)"""
+        lib, dev = self._lib, tok.device
+        di, st = dev.index or 0, torch.cuda.current_stream(dev).cuda_stream
+        T, H, n_cls = int(tok.shape[0]), self.hidden, int(first_d.shape[0])
+        s = torch.empty((T, H), dtype=torch.float16, device=dev)
+        if lib.rdx_enc_embed_f16(di, tok.data_ptr(), pos.data_ptr(), self.word.weight.data_ptr(), self.pos.weight.data_ptr(),
+                                 self.typ.weight.data_ptr(), T, H, s.data_ptr(), st):
+            raise RuntimeError("rdx_enc_embed_f16: " + self._last_error())
+        ln, last = self.ln, len(self.layers) - 1
+        for li, (wqkv, bqkv, dense_o, ln1, inter, out, ln2) in enumerate(self.layers):
+            y = torch.empty((T, H), dtype=torch.float16, device=dev)
+            qkv = self._stage(s, wqkv, bqkv, T, ln=ln, y_out=y, epi=0, pf=dense_o.weight)
+            ctx = torch.empty((T, H), dtype=torch.float16, device=dev)
+            if lib.rdx_enc_attention_small_f16(di, qkv.data_ptr(), tok_first.data_ptr(), T, self.heads, H // self.heads,
+                                               (H // self.heads) ** -0.5, ctx.data_ptr(), st):
+                raise RuntimeError("rdx_enc_attention_small_f16: " + self._last_error())
+            rows = None
+            if li == last:                                   # everything behind the last attention is row-wise: only the CLS rows are needed
+                rows, T = first_d, n_cls
+            s1 = self._stage(ctx, dense_o.weight, dense_o.bias, T, res=y, rows=rows, epi=2, fpb=self.stage_fpb_o, pf=inter.weight)
+            y1 = torch.empty((T, H), dtype=torch.float16, device=dev)
+            f = self._stage(s1, inter.weight, inter.bias, T, ln=ln1, y_out=y1, epi=1, pf=out.weight)
+            nxt = self.layers[li + 1][0] if li < last else None
+            s = self._stage(f, out.weight, out.bias, T, res=y1, epi=2, fpb=self.stage_fpb_f2, pf=nxt)
+            ln = ln2
+        o = torch.empty((n_cls, H), dtype=torch.float32, device=dev)
+        if lib.rdx_enc_layernorm_rows_f16(di, s.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps), n_cls, H, o.data_ptr(), st):
+            raise RuntimeError("rdx_enc_layernorm_rows_f16: " + self._last_error())
+        return o
+
     def _fused_forward(self, tok, pos, first_d, tok_first, tok_len, max_len: int = 0) -> torch.Tensor:
         """the forward on packed tokens with librdx's two kernels: [T] ids / positions -> fp32 [B][hidden] CLS rows"""
+        if self.small_stage and tok.shape[0] <= self.STAGE_TOKENS:
+            return self._small_forward(tok, pos, first_d, tok_first)
         F = torch.nn.functional
         x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
         last = len(self.layers) - 1
@@ -254,7 +314,7 @@ class _PackedEncoder:
             host["pk_tlen"] = torch.from_numpy(np.repeat(lens, lens).astype(np.int32))
             max_len = int(lens.max())
             if self.graphs and B <= self.SMALL_TEXTS:
-                g = self.SMALL_TOKEN_GRANULE
+                g = 16 if (self.small_stage and T <= 16) else self.SMALL_TOKEN_GRANULE   # (a question of <= 16 tokens: one token block per stage)
                 extra = -(-T // g) * g - T                       # one-token dummy texts behind the real ones
                 lb = 16 if max_len <= 16 else (32 if max_len <= 32 else 64)
                 padded = {"pk_tok": torch.cat([host["pk_tok"], torch.full((extra,), self.pad, dtype=torch.int64)]),
@@ -263,8 +323,9 @@ class _PackedEncoder:
                           "pk_tfirst": torch.cat([host["pk_tfirst"], torch.arange(T, T + extra, dtype=torch.int32)]),
                           "pk_tlen": torch.cat([host["pk_tlen"], torch.ones(extra, dtype=torch.int32)])}
                 out = self._replay(("small", T + extra, lb), padded, to_dev, lb)
-                if out is not None:
-                    return out[:B]
+                if out is None:   # shape not captured yet: the SAME padded tensors eagerly, so that call 1 and the replays run identical shapes
+                    out = self._fused_forward(*(to_dev(n, padded[n]) for n in self._ORDER), lb)
+                return out[:B]
             elif self.graphs is True:
                 out = self._replay((B, T, max_len), host, to_dev, max_len)   # (the longest text sizes the attention's LDS window: part of the shape)
                 if out is not None:
@@ -379,11 +440,22 @@ class EmbeddingProvider:
         return self
 
     def unload(self):
-        if self._model is not None:
-            self._model = None
-            self._tokenizer = None
-            if str(self.device).startswith("cuda"):
-                torch.cuda.empty_cache()
+        """frees the model's VRAM (reference src/utils/embedding_provider.py:107-114): the modules, the packed encoder's
+        concatenated QKV weights, its captured graphs (each holds a private memory pool) and scratch, the pinned staging rings"""
+        with self._lock:
+            if self._model is not None or self._packed is not None:
+                if self._packed is not None:
+                    self._packed._graph.clear()       # graphs first: their pools go back to the allocator
+                    self._packed._pad_buf.clear()
+                    self._packed.layers = []
+                self._packed = None
+                self._pinned.clear()
+                self._model = None
+                self._tokenizer = None
+                if str(self.device).startswith("cuda"):
+                    import gc
+                    gc.collect()
+                    torch.cuda.empty_cache()
 
     # Length buckets. sentence-transformers (the reference's encoder, src/utils/embedding_provider.py:139-145) sorts a call's texts by
     # length and pads every batch of `batch_size` to ITS longest text. With the large batches a GPU wants (BASELINE config 5 hands

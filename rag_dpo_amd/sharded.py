@@ -107,6 +107,8 @@ class ShardedSearcher:
     merge_packed(...) over the all-gather receive buffer and merge_flag(); optionally the asynchronous pair
     search_async(..., out_flags) / search_wait()."""
 
+    MERGE_MAX = 4096   # candidates per query rdx_merge_topk_packed ranks in one block (include/rdx.h): world * k must not exceed it
+
     def __init__(self, shard, group: Optional[dist.ProcessGroup] = None, device=None, host_staged: bool = False,
                  always_exchange: bool = False):
         self.shard = shard
@@ -182,6 +184,11 @@ class ShardedSearcher:
             raise ValueError("k must be >= 1")
         if self._open is not None:
             raise RuntimeError("search_begin() twice without search_end()")
+        if (self.world > 1 or self.always_exchange) and self.world * k > self.MERGE_MAX:
+            # checked BEFORE anything is enqueued: a rank that failed in the merge, behind an all-gather every other rank has
+            # entered, would leave them waiting (rdx_merge_topk_packed ranks world * k candidates per query in one block)
+            raise ValueError(f"sharded search: world * k = {self.world * k} exceeds {self.MERGE_MAX} candidates per query "
+                             f"(k <= {self.MERGE_MAX // self.world} at world {self.world}); use MultiDeviceIndex, whose merge folds")
         nq = queries.shape[0]
         if query_src is not None:
             self.broadcast_queries(queries, query_src)

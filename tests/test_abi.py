@@ -23,7 +23,7 @@ def test_header_symbols_are_exported_and_bound():
     for s in syms:
         assert hasattr(raw, s), f"{s} declared in include/rdx.h but not exported by librdx.so"
     assert sorted(_lib.SYMBOLS) == syms, "ctypes binding table and header disagree"
-    assert L.rdx_version() == _lib.ABI_VERSION == 2
+    assert L.rdx_version() == _lib.ABI_VERSION == 3
     assert ctypes.sizeof(_lib.SearchStats) == 8 * 7 + 4 * 2 + 4 * 7 + 4 + 8 * 3 + 4 * 4   # layout of rdx_search_stats (with padding)
 
 

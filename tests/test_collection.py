@@ -322,6 +322,45 @@ def test_failed_snapshot_leaves_the_store_on_its_old_generation(tmp_path, monkey
     assert got[0] == want[0] and (got[3] == want[3]).all()
 
 
+def test_snapshot_failing_after_its_commit_point_keeps_the_new_generation(tmp_path, monkeypatch):
+    """persist() whose header replace succeeded but whose directory fsync raised: collection.json on disk names
+    generation g+1, so its files must NOT be removed, the object must follow the header, and writes acknowledged afterwards must
+    be found again at the next open — a handler that deletes snap<g+1> there loses every row"""
+    import os
+    from rag_dpo_amd import collection as C
+    cl = _open(tmp_path)
+    col = cl.create_collection("rag_dpo_chunks", metadata={"hnsw:space": "cosine"})
+    emb = synth.make_corpus(40, 64)
+    col.add(ids=[f"a{i}" for i in range(10)], embeddings=emb[:10].tolist(), documents=[f"d{i}" for i in range(10)])
+    cl.persist()                                                  # generation 1
+    col.add(ids=["b0"], embeddings=emb[10:11].tolist())
+    gen = col._gen
+    real, calls = C._fsync_dir, []
+
+    def flaky(path):
+        calls.append(path)
+        if len(calls) == 2:                                       # 1st: before the header; 2nd: right after os.replace(collection.json)
+            raise OSError(5, "Input/output error")
+        return real(path)
+    monkeypatch.setattr(C, "_fsync_dir", flaky)
+    with pytest.raises(OSError):
+        cl.persist()
+    monkeypatch.undo()
+    assert len(calls) == 2
+    assert col._gen == gen + 1                                    # the object follows the header that is on disk
+    have = set(os.listdir(col._dir))
+    assert {f"snap{gen + 1}.embeddings.f32.npy", f"snap{gen + 1}.records.jsonl"} <= have
+    col.add(ids=["c0", "c1"], embeddings=emb[11:13].tolist(), documents=["x", "y"])   # acknowledged after the failure
+    col.delete(ids=["a4"])
+    want = _state(col)
+    got = _state(_open(tmp_path).get_collection("rag_dpo_chunks"))
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2] and (got[3] == want[3]).all()
+    assert "b0" in got[0] and "c1" in got[0] and "a4" not in got[0] and len(got[0]) == 12
+    cl.persist()
+    got = _state(_open(tmp_path).get_collection("rag_dpo_chunks"))
+    assert got[0] == want[0] and (got[3] == want[3]).all()
+
+
 def test_reload_keeps_stored_vectors_bit_for_bit(tmp_path):
     """snapshot rows are reloaded verbatim (engine.add_stored), not normalised a second time: distances before persist
     and after reopen are the same floats (the reference indexes in one process and serves from another)"""

@@ -363,13 +363,13 @@ def test_fused_encoder_kernels_equal_the_torch_operations():
         ref = plain.embed_device(texts)
         assert got.shape == ref.shape
         assert float((torch.nn.functional.normalize(got, dim=1) - torch.nn.functional.normalize(ref, dim=1)).abs().max()) <= 2e-3, texts
-    assert len(fast._packed._graph) == 1                    # all of them: <= 32 tokens, longest text <= 16 -> one canonical shape
+    assert len(fast._packed._graph) == 2                    # two canonical shapes: <= 16 tokens (one token block per stage) and <= 32
     a1, a2 = fast.embed_device(small[2]).clone(), fast.embed_device(small[2]).clone()
     assert torch.equal(a1, a2)
     many = [" ".join(f"w{i}" for i in range(j, j + 30)) for j in range(4)]      # 4 x 32 tokens: another canonical shape
     for _ in range(3):
         got = fast.embed_device(many).clone()
-    assert len(fast._packed._graph) == 2
+    assert len(fast._packed._graph) == 3
     assert float((torch.nn.functional.normalize(got, dim=1) - torch.nn.functional.normalize(plain.embed_device(many), dim=1)).abs().max()) <= 2e-3
     fast._packed.MAX_GRAPHS = 1                             # capturing a new shape pushes the least recently used ones out
     for _ in range(2):
@@ -377,6 +377,198 @@ def test_fused_encoder_kernels_equal_the_torch_operations():
     assert list(fast._packed._graph) == [("small", 192, 32)]
 
 
+
+
+@pytest.mark.gpu
+def test_encoder_stage_kernel_vs_fp32_reference():
+    """rdx_enc_stage_f16 (one projection of the single-question forward: LayerNorm prologue or plain / gathered input, the weight matrix
+    streamed once by workgroups of 16 / 8 / 4 features, bias / erf GELU / residual epilogue) against a plain torch fp32 reference of the
+    same op on the same fp16 inputs. Token counts 1..32 on both sides of the 16-token block, every K the kernel takes, with and without
+    the next stage's weight prefetch. Tolerance: fp16 output of fp32 accumulation (2e-3 relative to the row scale, as for
+    rdx_enc_linear_small_f16); the stored LayerNorm output within one fp16 ulp of torch's fp32 LayerNorm."""
+    import torch
+    from rag_dpo_amd import _lib
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(21)
+    nxt = torch.zeros(3 * 1024 * 1024, dtype=torch.float16, device="cuda")          # "the next stage's weights" (6 MB, only touched)
+    # LayerNorm prologue: qkv / FFN-up shapes
+    for T, N, K, epi in ((1, 3072, 1024, 0), (16, 4096, 1024, 1), (17, 3072, 1024, 0), (20, 4096, 1024, 1), (32, 3072, 1024, 0), (32, 1024, 512, 1), (9, 1536, 512, 0)):
+        s = (torch.randn((T, K), generator=g) * 1.7 + 0.3).half().cuda()
+        w = (torch.randn((N, K), generator=g) * K ** -0.5).half().cuda()
+        b = (torch.randn((N,), generator=g) * 0.1).half().cuda()
+        ln = torch.nn.LayerNorm(K, eps=1e-5)
+        with torch.no_grad():
+            ln.weight.copy_(torch.randn(K, generator=g) * 0.3 + 1)
+            ln.bias.copy_(torch.randn(K, generator=g) * 0.2)
+        ln = ln.half().cuda()
+        y_ref = torch.nn.functional.layer_norm(s.float(), (K,), ln.weight.float(), ln.bias.float(), 1e-5)
+        for pf in (0, nxt.numel() * 2):
+            out = torch.full((T, N), float("nan"), dtype=torch.float16, device="cuda")
+            y = torch.full((T, K), float("nan"), dtype=torch.float16, device="cuda")
+            rc = L.rdx_enc_stage_f16(0, s.data_ptr(), None, ln.weight.data_ptr(), ln.bias.data_ptr(), 1e-5, y.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                     None, T, N, K, epi, 0, nxt.data_ptr() if pf else None, pf, out.data_ptr(), st)
+            assert rc == 0, _lib.last_error()
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all() and torch.isfinite(y).all()
+            ulp = 2.0 ** -10 * torch.clamp(y_ref.abs(), min=1.0)
+            assert bool(((y.float() - y_ref).abs() <= ulp).all()), (T, N, K, float((y.float() - y_ref).abs().max()))
+            want = y.float() @ w.float().T + b.float()            # (from the fp16 LayerNorm output the kernel itself multiplies)
+            if epi:
+                want = torch.nn.functional.gelu(want)
+            err = float((out.float() - want).abs().max())
+            assert err <= 2e-3 * max(1.0, float(want.abs().max())), (T, N, K, epi, err)
+    # plain input: output projection / FFN-down shapes, residual epilogue, 16 / 8 / 4 features per workgroup, gathered rows
+    for T, N, K in ((1, 1024, 1024), (16, 1024, 4096), (20, 1024, 1024), (32, 1024, 4096), (27, 512, 1024), (32, 512, 2048), (5, 512, 512)):
+        rows_src = 40
+        x = torch.randn((rows_src, K), generator=g).half().cuda()
+        res = torch.randn((rows_src, N), generator=g).half().cuda()
+        w = (torch.randn((N, K), generator=g) * K ** -0.5).half().cuda()
+        b = (torch.randn((N,), generator=g) * 0.1).half().cuda()
+        idx = torch.randperm(rows_src, generator=g)[:T].cuda()
+        for fpb in (16, 8, 4):
+            for epi in (0, 1, 2):
+                for gather in (False, True):
+                    out = torch.full((T, N), float("nan"), dtype=torch.float16, device="cuda")
+                    rc = L.rdx_enc_stage_f16(0, x.data_ptr(), idx.data_ptr() if gather else None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(),
+                                             res.data_ptr(), T, N, K, epi, fpb, nxt.data_ptr(), 1 << 20, out.data_ptr(), st)
+                    assert rc == 0, _lib.last_error()
+                    xs, rs = (x[idx], res[idx]) if gather else (x[:T], res[:T])
+                    want = xs.float() @ w.float().T + b.float()
+                    if epi == 1:
+                        want = torch.nn.functional.gelu(want)
+                    if epi == 2:
+                        want = want.half().float() + rs.float()
+                    torch.cuda.synchronize()
+                    assert torch.isfinite(out).all()
+                    err = float((out.float() - want).abs().max())
+                    assert err <= 3e-3 * max(1.0, float(want.abs().max())), (T, N, K, fpb, epi, gather, err)
+    # argument checks
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 33, N, K, 0, 16, None, 0, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, 768, 0, 16, None, 0, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, K, 2, 16, None, 0, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, K, 0, 5, None, 0, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 0, N, K, 0, 16, None, 0, out.data_ptr(), 0) == 0
+
+
+@pytest.mark.gpu
+def test_encoder_attention_small_kernel_vs_fp32_reference():
+    """rdx_enc_attention_small_f16 (at most 32 packed tokens, QK^T and PV on MFMA, one workgroup per head) against the plain fp32 torch
+    reference of the same op: one text of 1..32 tokens, several short texts, the canonical padded shape (real texts + one-token dummies).
+    Tolerance 3e-3: fp16 output, probabilities rounded to fp16 before the PV product."""
+    import torch
+    from rag_dpo_amd import _lib
+    L = _lib.load()
+    for heads, lens in ((16, [20]), (16, [1]), (8, [32]), (16, [16]), (16, [17]), (4, [5, 1, 9, 3]), (16, [22] + [1] * 10), (8, [7, 6, 1, 1, 1]), (2, [15, 16])):
+        H, T = heads * 64, int(sum(lens))
+        g = torch.Generator().manual_seed(100 + T + heads)
+        qkv = (torch.randn((T, 3 * H), generator=g) * 1.5).half()
+        first = np.cumsum(lens) - np.asarray(lens)
+        tf = torch.from_numpy(np.repeat(first, lens).astype(np.int32)).cuda()
+        qd = qkv.cuda()
+        ctx = torch.full((T, H), float("nan"), dtype=torch.float16, device="cuda")
+        rc = L.rdx_enc_attention_small_f16(0, qd.data_ptr(), tf.data_ptr(), T, heads, 64, 0.125, ctx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _lib.last_error()
+        want = _attention_reference(qkv, [int(n) for n in lens], heads)
+        torch.cuda.synchronize()
+        got = ctx.float().cpu()
+        assert torch.isfinite(got).all()
+        assert float((got - want).abs().max()) <= 3e-3, (heads, lens, float((got - want).abs().max()))
+    assert L.rdx_enc_attention_small_f16(0, qd.data_ptr(), tf.data_ptr(), 33, heads, 64, 0.125, ctx.data_ptr(), 0) != 0
+    assert L.rdx_enc_attention_small_f16(0, qd.data_ptr(), tf.data_ptr(), T, heads, 32, 0.125, ctx.data_ptr(), 0) != 0
+
+
+@pytest.mark.gpu
+def test_encoder_embed_and_last_layernorm_kernels():
+    """rdx_enc_embed_f16 = the module's embedding sum (two fp16 adds in its order: bit-equal to torch); rdx_enc_layernorm_rows_f16 = torch's
+    fp16 LayerNorm widened to fp32 (within one fp16 ulp of the fp32 LayerNorm)."""
+    import torch
+    from rag_dpo_amd import _lib
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3)
+    for H in (512, 1024, 2048):
+        word = torch.randn((300, H), generator=g).half().cuda()
+        pos = torch.randn((60, H), generator=g).half().cuda()
+        typ = torch.randn((1, H), generator=g).half().cuda()
+        tok = torch.randint(0, 300, (23,), generator=g).cuda()
+        pid = torch.randint(0, 60, (23,), generator=g).cuda()
+        out = torch.empty((23, H), dtype=torch.float16, device="cuda")
+        assert L.rdx_enc_embed_f16(0, tok.data_ptr(), pid.data_ptr(), word.data_ptr(), pos.data_ptr(), typ.data_ptr(), 23, H, out.data_ptr(), st) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out, word[tok] + pos[pid] + typ[0])
+        s = (torch.randn((9, H), generator=g) * 2 + 0.5).half().cuda()
+        gamma, beta = (torch.randn(H, generator=g) * 0.3 + 1).half().cuda(), (torch.randn(H, generator=g) * 0.2).half().cuda()
+        o32 = torch.empty((9, H), dtype=torch.float32, device="cuda")
+        assert L.rdx_enc_layernorm_rows_f16(0, s.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 9, H, o32.data_ptr(), st) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        ref = torch.nn.functional.layer_norm(s.float(), (H,), gamma.float(), beta.float(), 1e-5)
+        assert bool(((o32 - ref).abs() <= 2.0 ** -10 * torch.clamp(ref.abs(), min=1.0)).all())
+        assert torch.equal(o32, o32.half().float())               # values of an fp16 LayerNorm output
+    assert L.rdx_enc_embed_f16(0, tok.data_ptr(), pid.data_ptr(), word.data_ptr(), pos.data_ptr(), typ.data_ptr(), 23, 768, out.data_ptr(), 0) != 0
+
+
+@pytest.mark.gpu
+def test_single_question_forward_vs_module_forward():
+    """the reference's online path, `embed_query` in front of every search (src/rag/retriever.py:150-154): the five-launches-per-layer
+    forward of one question against `XLMRobertaModel.forward` of the same weights in fp16 AND in fp32 — |1 - cos| <= 1e-5 against the
+    fp16 module, <= 2e-5 against fp32 — for questions on both sides of the 16-token block and for a question's sub-queries embedded
+    together; the first call of a shape (eager) and its replays (HIP graph) return the same bits; full-size XLM-R-large once."""
+    import torch
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    words = [f"w{i}" for i in range(64)]
+    qs = [" ".join(words[:n]) for n in (1, 5, 13, 14, 15, 22, 30)]
+    for name in ("random-init:mid", "random-init:xlm-roberta-large"):
+        fast = EmbeddingProvider(model_name=name, device="cuda:0", dtype=torch.float16).load()
+        assert fast._packed.small_stage
+        mod16 = EmbeddingProvider(model_name=name, device="cuda:0", dtype=torch.float16)
+        mod16.packed_forward = False
+        mod16.load()
+        mod32 = None
+        if name.endswith("mid"):
+            mod32 = EmbeddingProvider(model_name=name, device="cuda:0", dtype=torch.float32)
+            mod32.packed_forward = False
+            mod32.load()
+        for batch in [[q] for q in qs] + [[qs[1], qs[0], qs[2]], qs[:4]]:
+            first = fast.embed_device(batch).clone()
+            again = [fast.embed_device(batch).clone() for _ in range(3)]      # capture, replay, replay
+            for a in again:
+                assert torch.equal(a, first), batch
+            ref = mod16.embed_device(batch)
+            cos = torch.nn.functional.cosine_similarity(first.double(), ref.double(), dim=1)
+            assert float((1 - cos).abs().max()) <= 1e-5, (name, batch, float((1 - cos).abs().max()))
+            if mod32 is not None:
+                cos = torch.nn.functional.cosine_similarity(first.double(), mod32.embed_device(batch).double(), dim=1)
+                assert float((1 - cos).abs().max()) <= 2e-5, (name, batch, float((1 - cos).abs().max()))
+        assert len(fast._packed._graph) >= 2
+        for p in (fast, mod16, mod32):
+            if p is not None:
+                p.unload()
+
+
+@pytest.mark.gpu
+def test_unload_frees_the_model_memory():
+    """`unload()` exists to give the VRAM back (reference src/utils/embedding_provider.py:107-114): modules, the packed encoder's
+    concatenated QKV copies, captured graphs and their pools, scratch, pinned staging"""
+    import gc
+    import torch
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    gc.collect()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated(0)
+    p = EmbeddingProvider(model_name="random-init:mid", device="cuda:0", dtype=torch.float16).load()
+    for _ in range(3):
+        p.embed(["w1 w2 w3"])
+        p.embed(["w1 w2 w3 w4 w5 w6 w7 w8 w9 w10 w11 w12 w13 w14 w15 w16 w17 w18", "w2"])
+    p.embed([" ".join(f"w{i}" for i in range(90))] * 3)
+    loaded = torch.cuda.memory_allocated(0)
+    assert loaded > base + 10 * 2 ** 20 and len(p._packed._graph) >= 1
+    p.unload()
+    assert not p.is_loaded and p._packed is None and not p._pinned
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated(0) <= base + 2 ** 20, (base, loaded, torch.cuda.memory_allocated(0))
+    assert len(p.embed(["w1 w2"])[0]) == p.dims                  # and loads again on demand, like the reference's lazy load
 
 
 @pytest.mark.gpu

@@ -116,6 +116,15 @@ def _worker(rank, world, port, n, dim, b, k, out_dir):
         raise AssertionError("search_end() without search_begin() accepted")
     except RuntimeError:
         pass
+    # world * k beyond what the packed merge ranks per query: refused on every rank BEFORE anything is enqueued (a
+    # rank failing in the merge, behind an all-gather the others have entered, would hang them)
+    n_ex = ss.exchanges
+    try:
+        ss.search_begin(q, ShardedSearcher.MERGE_MAX // world + 1)
+        raise AssertionError("world * k > MERGE_MAX accepted")
+    except ValueError:
+        pass
+    assert ss._open is None and ss.exchanges == n_ex
     # asynchronous form: rank 1's first pass is incomplete for queries 2 and 5 (every other rank's is complete) — all ranks
     # must repeat the exchange and end with the same, complete result; with nothing late nobody repeats it
     # The decision travels in the flags word of the packed partials (no collective besides the all-gather): every rank
