@@ -9,7 +9,8 @@ while N grows (strong scaling: BASELINE.json config "10M x 1024 row-sharded over
     python bench.py [--gpus N --steps K --warmup W] [--workload c4|c3|c2|c5|c1] [--rows R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line. Extra keys beyond the contract: roofline, cpu_baseline, recall_at_10, path_stats.
+Rank 0 prints ONE JSON line. Extra keys beyond the contract: roofline, cpu_baseline, recall_at_10, path_stats,
+other_configs (c1 / c2 / c3 as short legs behind the timed region of the default c4 run).
 """
 from __future__ import annotations
 
@@ -52,14 +53,18 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_shard(shard: HipShard, lo: int, hi: int, dim: int, corpus_kind: str, device, total_rows: int):
+def build_shard(shard: HipShard, lo: int, hi: int, dim: int, corpus_kind: str, device, total_rows: int, shape: str = "iid"):
     """this rank's rows [lo, hi) of the deterministic synthetic corpus of SURVEY.md §8(d) (N(0,1) rows, 1 % exact
-    duplicates), generated in HBM chunk by chunk"""
+    duplicates), generated in HBM chunk by chunk. shape "embed": the embedding-like corpus of synth.torch_embedlike_chunk
+    (a common mean direction, documents of contiguous near-duplicate chunks) instead"""
     shard.index.reserve(hi - lo)
     j0, j1 = lo // synth.CHUNK, (hi + synth.CHUNK - 1) // synth.CHUNK
     for j in range(j0, j1):
         r0 = j * synth.CHUNK
-        rows = synth.torch_corpus_chunk(j, min(synth.CHUNK, total_rows - r0), dim, device)
+        if shape == "embed":
+            rows = synth.torch_embedlike_chunk(j, min(synth.CHUNK, total_rows - r0), dim, device, total_rows)
+        else:
+            rows = synth.torch_corpus_chunk(j, min(synth.CHUNK, total_rows - r0), dim, device)
         a, b = max(lo, r0) - r0, min(hi, r0 + synth.CHUNK) - r0
         rows = rows[a:b].contiguous()
         if corpus_kind == "bf16":
@@ -154,6 +159,70 @@ def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, to
     return cpu, rec
 
 
+def run_other_config(name: str, device, steps: int, warmup: int) -> dict:
+    """One more BASELINE config in the same process, AFTER the timed region of the line's own workload (never inside it): its own
+    index, `steps` timed searches with the corpus and the queries resident, the dominant kernel timed by librdx's HIP events on the
+    search's stream, and the ids / score bits of a few queries compared with the C oracle (the whole corpus where that takes a
+    second, otherwise the first 131 072 rows selected by bitmap). Same formulas as the main line's `roofline`."""
+    from oracle import oracle as O
+    O.build()
+    wl = WORKLOADS[name]
+    rows, dim, B, k = wl["rows"], wl["dim"], wl["batch"], wl["k"]
+    t0 = time.time()
+    sh = HipShard(dim, device.index or 0, row_offset=0)
+    try:
+        build_shard(sh, 0, rows, dim, wl["corpus"], device, rows)
+        se = ShardedSearcher(sh)
+        q = synth.torch_queries(B, dim, device, total_rows=rows)
+        sh.index.set_option("profile", 2)
+        for _ in range(warmup):
+            se.search(q, k)
+        torch.cuda.synchronize(device)
+        scan_ms = exact_ms = 0.0
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            se.search(q, k)
+            st = sh.index.last_stats_struct()
+            scan_ms += st.ms_scan_main
+            exact_ms += st.ms_exact
+        torch.cuda.synchronize(device)
+        ms_step = (time.perf_counter() - t1) / steps * 1e3
+        stats = sh.index.last_stats()
+        dim_pad = (dim + 63) // 64 * 64
+        if stats["path"] == 0:
+            kern_ms = scan_ms / steps
+            flops, by = 2.0 * B * rows * dim_pad, rows * dim_pad * 2.0 + B * dim_pad * 2.0
+            if flops / (PEAK_MFMA_TFLOPS * 1e12) >= by / (PEAK_HBM_GBS * 1e9):
+                bound, frac = "mfma", flops / (kern_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS
+            else:
+                bound, frac = "hbm", by / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+            kernel = "main scan (k_scan / k_scan_small)"
+        else:
+            kern_ms = exact_ms / steps
+            by = -(-B // 4) * rows * dim * 4.0 + B * rows * 4.0 * 2
+            bound, frac, kernel = "hbm", by / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "k_exact_scores + k_select_dense (exact path)"
+        # the checker: ids and score bits against the C oracle
+        nchk = min(B, 8)
+        qh = q[:nchk].cpu().numpy()
+        sample = rows if rows <= 131_072 else 131_072
+        rows_hat = sh.index.get(np.arange(sample, dtype=np.int64))
+        es, er, ec = O.cosine_topk(rows_hat, qh, k)
+        allow = None
+        if sample < rows:
+            a = np.zeros(rows, dtype=bool)
+            a[:sample] = True
+            allow = O.pack_mask(a, rows)
+        gs, gr, gc = sh.index.search(qh, k, allow)
+        exact = bool((gr == er).all() and (gs == es).all() and (gc == ec).all())
+        return {"workload": wl["desc"], "steps": steps, "ms_per_step": round(ms_step, 4), "queries_per_s": round(B / ms_step * 1e3, 1),
+                "main_kernel": kernel, "main_kernel_ms": round(kern_ms, 4), "bound": bound, "frac": round(frac, 4),
+                "ids_bit_exact_vs_oracle": exact, "oracle_check": f"{nchk} queries x {sample} rows" + ("" if sample == rows else " (bitmap-selected sample)"),
+                "emitted_per_query": round(stats["emitted"] / max(1, B), 1), "retried_queries": stats["retried_queries"],
+                "exact_fallback_queries": stats["exact_queries"], "build_and_run_s": round(time.time() - t0, 2)}
+    finally:
+        sh.index.close()
+
+
 def self_launch(n: int) -> int:
     import socket
     import subprocess
@@ -181,9 +250,9 @@ def self_launch(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 20 for c4 / c5; 200 for c3, 500 for c1 / c2, whose steps are "
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 100 for c4, 20 for c5; 200 for c3, 500 for c1 / c2, whose steps are "
                                                          "fractions of a millisecond: 20 of them end before the clocks have ramped)")
-    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps first (default: 3; 20 / 50 for the small workloads)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed steps first (default: 20 for c4, 3 for c5; 20 / 50 for the small workloads)")
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--rows", type=int, default=0, help="override the workload's total corpus rows")
     ap.add_argument("--batch", type=int, default=0)
@@ -206,6 +275,10 @@ def main():
     ap.add_argument("--check-merged", action="store_true",
                     help="N>1: rank 0 also builds the WHOLE corpus in one index and checks that the merged result is bit-identical "
                          "(the default cross-rank exactness leg needs no second copy of the corpus)")
+    ap.add_argument("--corpus-shape", choices=["iid", "embed"], default="iid",
+                    help="iid: SURVEY.md §8d's N(0,1) corpus (the judged line). embed: an embedding-like corpus — a common mean direction (unrelated rows "
+                         "have cosine ~0.5) and 2000 documents of contiguous near-duplicate chunks, queries near documents (rag_dpo_amd/synth.py)")
+    ap.add_argument("--no-others", action="store_true", help="c4, N=1: skip the short legs of configs c1 / c2 / c3 behind the timed region (other_configs)")
     ap.add_argument("--no-check", action="store_true", help="N>1 / --force-dist: skip the cross-rank exactness leg and the step breakdown")
     args = ap.parse_args()
 
@@ -243,9 +316,9 @@ def main():
             dist.init_process_group("nccl", device_id=device)   # nccl == RCCL on ROCm
 
     if args.steps <= 0:
-        args.steps = {"c1": 500, "c2": 500, "c3": 200}.get(args.workload, 20)
-    if args.warmup < 0:
-        args.warmup = {"c1": 50, "c2": 50, "c3": 20}.get(args.workload, 3)
+        args.steps = {"c1": 500, "c2": 500, "c3": 200, "c4": 100}.get(args.workload, 20)    # (>= 100 timed batches behind
+    if args.warmup < 0:                                                                       #  >= 20 warm-up ones; the driver passes its own)
+        args.warmup = {"c1": 50, "c2": 50, "c3": 20, "c4": 20}.get(args.workload, 3)
     wl = dict(WORKLOADS[args.workload])
     if args.rows:
         wl["rows"] = args.rows
@@ -260,10 +333,13 @@ def main():
     shard = HipShard(dim, local_rank, row_offset=lo)
     if wl["corpus"] == "bf16" and not args.fp32_master:
         shard.index.set_option("compact_master", 1)   # config 5: raw bf16 rows + divisors as the exact copy: 4 B/element in HBM
-    build_shard(shard, lo, hi, dim, wl["corpus"], device, rows)
+    build_shard(shard, lo, hi, dim, wl["corpus"], device, rows, shape=args.corpus_shape)
     log(f"[rank {rank}] shard rows [{lo}, {hi}) resident in {time.time() - t_build:.1f}s")
     searcher = ShardedSearcher(shard, host_staged=rehearsal, always_exchange=args.force_dist)
-    queries, planted = synth.torch_queries(B, dim, device, total_rows=rows, return_planted=True)   # 10 % planted (§8d)
+    if args.corpus_shape == "embed":
+        queries, planted = synth.torch_embedlike_queries(B, dim, device)[0], None
+    else:
+        queries, planted = synth.torch_queries(B, dim, device, total_rows=rows, return_planted=True)   # 10 % planted (§8d)
     # ONE query batch for all ranks: rank 0's, broadcast once, outside the timed region (the rank that took the
     # request hands it to the others). Nothing rests on every rank's generator producing the same bits.
     if world > 1 or args.force_dist:
@@ -545,7 +621,7 @@ def main():
         if world == 1 and stats and stats["path"] == 0:
             try:
                 bs = 64
-                qs = synth.torch_queries(bs, dim, device, total_rows=rows)
+                qs = synth.torch_queries(bs, dim, device, total_rows=rows) if args.corpus_shape == "iid" else synth.torch_embedlike_queries(bs, dim, device)[0]
                 for _ in range(2):
                     searcher.search(qs, k)
                 torch.cuda.synchronize(device)
@@ -593,6 +669,16 @@ def main():
                         "note": "PCIe-inclusive rate (host numpy in -> host numpy out through rdx_search RDX_HOST); reported, never `value`"}
             except Exception as e:
                 log(f"pcie leg failed: {e!r}")
+        # the other single-GPU BASELINE configs, short legs in the same process AFTER everything timed above
+        others = None
+        if world == 1 and args.workload == "c4" and args.corpus_shape == "iid" and not args.no_others and not args.rows and not args.batch and not args.k:
+            others = {}
+            for name, n_steps, n_warm in (("c2", 500, 50), ("c3", 200, 20), ("c1", 500, 50)):
+                try:
+                    others[name] = run_other_config(name, device, n_steps, n_warm)
+                except Exception as e:   # a failing extra leg must not take the line down
+                    log(f"other_configs leg {name} failed: {e!r}")
+                    others[name] = {"error": repr(e)}
         cpu, rec = None, None
         if world == 1 and not args.no_cpu:
             try:
@@ -607,10 +693,12 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}", "rows_total": rows, "rows_per_gpu": n_local, "dim": dim,
                        "batch": B, "k": k, "corpus_dtype": wl["corpus"],
                        "hbm_bytes_per_element": (4 if (wl["corpus"] == "bf16" and not args.fp32_master) else 6),
-                       "synthetic_inputs": "SURVEY.md §8d: N(0,1) rows with 1 % exact duplicate rows, N(0,1) queries with 10 % planted next to a row",
+                       "synthetic_inputs": ("SURVEY.md §8d: N(0,1) rows with 1 % exact duplicate rows, N(0,1) queries with 10 % planted next to a row" if args.corpus_shape == "iid" else
+                                            "embedding-like: row = mu + d_doc + sigma_doc * eps (unrelated rows: cosine ~0.5), 2000 documents of contiguous chunks with "
+                                            "sigma_doc in [0.2, 0.6], every query near one document (rag_dpo_amd/synth.py torch_embedlike_chunk)"),
                        "parallelism": f"row-shard x{world} + all-gather merge"},
             "roofline": roof, "roofline_small_batch": small, "pcie_inclusive": pcie, "cpu_baseline": cpu, "recall_at_10": rec,
-            "merged_equals_single_index": merged_ok, "rccl": rccl_info, "distributed_check": dist_check, "step_breakdown": step_breakdown,
+            "other_configs": others, "merged_equals_single_index": merged_ok, "rccl": rccl_info, "distributed_check": dist_check, "step_breakdown": step_breakdown,
             "encode": ({"model": "XLM-R-large (BGE-M3 architecture), random-init fp16, hashing tokenizer", "texts_per_step": B,
                         "avg_ms": round(sum(a.elapsed_time(b) for a, b in enc_ev) / max(1, len(enc_ev)), 3),
                         "pipelined_with_search": bool(serial is not None), "serial_leg": serial,

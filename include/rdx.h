@@ -126,6 +126,9 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * main scan with the split-K kernel too (balanced in 32-row units instead of whole 256-row tiles);
  * "half_boot" 0/1 (default 1): searches of 129..256 queries take their threshold sample as two 128-query tiles per sampled corpus
  * tile (every CU busy, less data per k-step) instead of one 256-query tile on half the CUs;
+ * "spread_boot" 0/1 (default 1): searches of more than 64 queries take their threshold sample as every div-th 32-row block of the corpus
+ * instead of every div-th 256-row tile (the same number of rows, eight times finer: runs of similar rows stored together — a
+ * document's chunks — are met by the sample instead of falling between two sampled tiles; speed only);
  * "fuse_finish" 0/1 (default 1): the end-of-search work (counters and small results to pinned host memory) runs in the last
  * block of the search's last kernel instead of a launch of its own (both: speed only);
  * "retry" 0/1 (default 1): queries whose candidate
@@ -160,6 +163,13 @@ int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out
 int rdx_enc_attention_f16(int device, const void* qkv, const int32_t* tok_first, const int32_t* tok_len,
                           int64_t n_tokens, int heads, int head_dim, float scale, int max_text_tokens, void* ctx,
                           void* stream);
+/* rdx_enc_attention_mfma_f16: the same attention for texts of ANY length (the corpus side: chunk texts of up to ~1 K tokens, reference
+ *   src/processing/create_chromadb_index.py:300-387) on the matrix cores, flash-style. query_blocks [n_blocks][4] int32 =
+ *   {first token of the text, its length, first query of this block within the text, 0}: one workgroup per block of <= 64 queries and
+ *   head; the caller lists ceil(length / 64) blocks per text. Same arithmetic contract as rdx_enc_attention_f16 (soft-max and
+ *   accumulation in fp32; probabilities rounded to fp16 before the PV product, as a flash kernel does). */
+int rdx_enc_attention_mfma_f16(int device, const void* qkv, const int32_t* query_blocks, int n_blocks, int heads,
+                               int head_dim, float scale, void* ctx, void* stream);
 int rdx_enc_add_layernorm_f16(int device, const void* a, const void* b, const void* gamma, const void* beta,
                               float eps, int64_t rows, int hidden, void* out, void* stream);
 /* rdx_enc_linear_small_f16: out[n_tokens][n_out] = act(x[n_tokens][n_in] w[n_out][n_in]^T + bias[n_out]) for at most 256 tokens (one
@@ -185,8 +195,6 @@ int rdx_enc_linear_small_f16(int device, const void* x, const void* w, const voi
  *     ln_gamma == NULL: in = x, or rows x_rows[t] of x (and of `res`) when x_rows != NULL (the last layer: CLS rows only).
  *     epilogue 0: + bias; 1: erf GELU(+ bias); 2: res + (fp16)(+ bias) — the block's residual sum, rounded as the module's
  *       fp16 add rounds it; `out` then holds the next LayerNorm's input.
- *     prefetch / prefetch_bytes: the NEXT stage's weight matrix (or NULL / 0): waves that are done touch it so that it waits in
- *       the Infinity Cache (speed only).
  * rdx_enc_attention_small_f16: rdx_enc_attention_f16 for at most 32 tokens on MFMA, one workgroup per head: token t attends to
  *   the tokens u with tok_first[u] == tok_first[t].
  * rdx_enc_layernorm_rows_f16: out[r] (fp32) = (fp16) LayerNorm(s[r]) — the last LayerNorm, on the CLS rows. */
@@ -194,8 +202,7 @@ int rdx_enc_embed_f16(int device, const int64_t* tok, const int64_t* pos_id, con
                       const void* type0, int n_tokens, int hidden, void* out, void* stream);
 int rdx_enc_stage_f16(int device, const void* x, const int64_t* x_rows, const void* ln_gamma, const void* ln_beta,
                       float ln_eps, void* y_out, const void* w, const void* bias, const void* res, int n_tokens,
-                      int n_out, int n_in, int epilogue, int features_per_workgroup, const void* prefetch,
-                      int64_t prefetch_bytes, void* out, void* stream);
+                      int n_out, int n_in, int epilogue, int features_per_workgroup, void* out, void* stream);
 int rdx_enc_attention_small_f16(int device, const void* qkv, const int32_t* tok_first, int n_tokens, int heads,
                                 int head_dim, float scale, void* ctx, void* stream);
 int rdx_enc_layernorm_rows_f16(int device, const void* s, const void* gamma, const void* beta, float eps, int rows,

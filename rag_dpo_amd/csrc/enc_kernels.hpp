@@ -287,3 +287,149 @@ __global__ __launch_bounds__(NW * 64) void k_enc_linear_small(const _Float16* __
 }
 
 }  // namespace rdx
+
+namespace rdx {
+
+// E12 k_enc_attention_mfma: self-attention of packed texts of ANY length (the corpus side: the indexer embeds `heading\n\ntext` chunks of
+//    up to ~1 K tokens, reference src/processing/create_chromadb_index.py:300-387, src/utils/embedding_provider.py:30-31,136-145) on the
+//    matrix cores, flash-style: no padding, no scatter / gather / transpose passes around it, scores never leave the registers.
+//    Work unit = (64 consecutive queries of one text, head): 4 waves x 16 queries; the text's keys and values pass through LDS in tiles of
+//    32 (two buffers, the next tile's global loads in flight under the current tile's arithmetic, one barrier per tile).
+//      S^T = K Q^T   A = a K tile's rows (16 keys x 32 dims per MFMA, ds_read_b128 from a swizzled image), B = the wave's Q fragments
+//                    (registers for the whole kernel): the lane holds, for ITS query, the scores of keys 4g + r and 16 + 4g + r.
+//      online soft-max per query = per lane: 8 local values + two cross-lane maxima per tile; the running sum stays lane-partial
+//                    (the rescale factor is the query's, i.e. equal in the four lanes that share it) and is reduced once at the end.
+//      O^T += V^T P^T  P^T (fp16) IS the B operand as it stands (k position 8g + j <-> key 4g + j | 16 + 4g + j - 4); V^T comes out of the
+//                    row-major V tile by ds_read_b64_tr_b16 (the hardware's transposed read: lane i of a 16-lane group receives column i
+//                    of 4 rows) in exactly that key order; 16-byte chunks of a V row are stored XOR-ed with (key >> 1) & 3 on their
+//                    16-dim block index, which makes the 32 eight-byte reads of a half-wave hit 32 different bank pairs.
+//    qb[i] = {first token of the text, its length, first query (within the text) of unit i, 0}. Roofline: MFMA for long texts
+//    (4 * len^2 * 64 flop per text and head); measured in profiles/r04/ingest*.json.
+constexpr int ATT_KT = 32;
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__global__ __launch_bounds__(256) void k_enc_attention_mfma(const _Float16* __restrict__ qkv, const int32_t* __restrict__ qb, int heads, float scale_log2,
+                                                            _Float16* __restrict__ ctx) {
+    __shared__ __attribute__((aligned(16))) _Float16 ks[2][ATT_KT * 64];
+    __shared__ __attribute__((aligned(16))) _Float16 vs[2][ATT_KT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int first = qb[4 * blockIdx.x], len = qb[4 * blockIdx.x + 1], q0 = qb[4 * blockIdx.x + 2];
+    const int h = blockIdx.y;
+    const int64_t H = (int64_t)heads * 64, row = 3 * H;
+    const int qi = q0 + wave * 16 + l15;
+    half8 bq[2];
+    {
+        const _Float16* qp = qkv + (int64_t)(first + (qi < len ? qi : len - 1)) * row + h * 64 + g * 8;
+        bq[0] = *reinterpret_cast<const half8*>(qp);
+        bq[1] = *reinterpret_cast<const half8*>(qp + 32);
+    }
+    // staging: thread -> (key tid >> 3 of the tile, 16-byte chunk tid & 7 of its K row and of its V row)
+    const int sk = threadIdx.x >> 3, sc = threadIdx.x & 7;
+    const int k_slot = (sk * 8 + (sc ^ ((sk >> 1) & 7))) * 8;                                   // halves
+    const int v_slot = sk * 64 + ((((sc >> 1) ^ ((sk >> 1) & 3)) << 1) | (sc & 1)) * 8;
+    const _Float16* kv0 = qkv + (int64_t)first * row + H + h * 64 + sc * 8;
+    half8 kr, vr;
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+        const int key = t * ATT_KT + sk;
+        if (key < len) {
+            const _Float16* p = kv0 + (int64_t)key * row;
+            kr = *reinterpret_cast<const half8*>(p);
+            vr = *reinterpret_cast<const half8*>(p + H);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kr[e] = vr[e] = (_Float16)0.f;   // (a masked key has weight 0: its value must be finite)
+        }
+    };
+    const int ntiles = (len + ATT_KT - 1) / ATT_KT;
+    load_tile(0);
+    *reinterpret_cast<half8*>(&ks[0][k_slot]) = kr;
+    *reinterpret_cast<half8*>(&vs[0][v_slot]) = vr;
+    __syncthreads();
+    float m = -INFINITY, lpart = 0.f;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // addresses of this lane's reads inside a tile (halves)
+    int ka[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int r = kt * 16 + l15;
+            ka[kt][s] = (r * 8 + ((s * 4 + g) ^ ((r >> 1) & 7))) * 8;
+        }
+    const int tq = l15 >> 2, tp = l15 & 3;   // transposed read: lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p + 3 of the block
+    int va[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * 16 + 4 * g + tq;
+        va[j] = r * 64 + tp * 4;              // + the swizzled 16-dim block, per dt, below
+    }
+    const int vsw0 = ((4 * g + tq) >> 1) & 3, vsw1 = ((16 + 4 * g + tq) >> 1) & 3;
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) load_tile(t + 1);
+        f32x4 st[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&ks[buf][ka[kt][0]]), bq[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const half8*>(&ks[buf][ka[kt][1]]), bq[1], st[kt], 0, 0, 0);
+        }
+        float sc8[2][4];
+        float mt = -INFINITY;
+        const int kbase = t * ATT_KT + 4 * g;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc8[kt][r] = (kbase + kt * 16 + r < len) ? st[kt][r] * scale_log2 : -INFINITY;
+                mt = fmaxf(mt, sc8[kt][r]);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt);               // finite: every tile holds at least one real key
+        const float corr = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float psum = 0.f;
+        half8 pb;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(sc8[kt][r] - mn);
+                psum += p;
+                pb[kt * 4 + r] = (_Float16)p;
+            }
+        lpart = lpart * corr + psum;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            o[dt] *= corr;
+            const fp16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(&vs[buf][va[0] + ((dt ^ vsw0) << 4)]));
+            const fp16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(&vs[buf][va[1] + ((dt ^ vsw1) << 4)]));
+            const half8 av = {(_Float16)v0[0], (_Float16)v0[1], (_Float16)v0[2], (_Float16)v0[3], (_Float16)v1[0], (_Float16)v1[1], (_Float16)v1[2], (_Float16)v1[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, pb, o[dt], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) {
+            *reinterpret_cast<half8*>(&ks[buf ^ 1][k_slot]) = kr;
+            *reinterpret_cast<half8*>(&vs[buf ^ 1][v_slot]) = vr;
+        }
+        __syncthreads();
+    }
+    float l = lpart;
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (qi < len) {
+        const float inv = 1.f / l;
+        _Float16* op = ctx + (int64_t)(first + qi) * H + h * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            half4 r4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r4[r] = (_Float16)(o[dt][r] * inv);
+            *reinterpret_cast<half4*>(op + dt * 16) = r4;
+        }
+    }
+}
+
+}  // namespace rdx

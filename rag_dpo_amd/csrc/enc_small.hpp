@@ -21,8 +21,9 @@
 // weight rows straight into MFMA A fragments with everything in flight before the first MFMA, activations are the B operand (token
 // on the lane), the 16 partial tiles meet in LDS slabs and are added in wave order (deterministic), bias / GELU / residual in fp32.
 // Roofline: HBM, N*K*2 B per launch (the weight matrix once); what the kernel actually waits for is latency.
-// Waves 4..15, idle after the slab hand-off, touch the NEXT stage's weights (LDS-DMA into a scratch slot nobody reads): the weights
-// depend on no activation, so they can wait in the Infinity Cache when the next launch starts.
+// (Measured and dropped, DESIGN.md §10: the idle waves touching the NEXT stage's weights — every kernel then ends later by those
+// loads' latency, +0.08 ms per question — and the same chain as kernels on two streams handing over through counters in device memory,
+// 1.46 against 0.95 ms: profiles/r04/enc_chain_*.)
 #pragma once
 #include "enc_kernels.hpp"
 
@@ -40,8 +41,6 @@ struct EncStage {
     const _Float16* res;     // EPI 2: residual [rows][N]
     _Float16* out;           // [T][N]
     int T, N;
-    const char* pf;          // next stage's weights (or NULL) ...
-    uint32_t pf_bytes;       // ... and how many bytes of them to touch (a multiple of 1024)
 };
 
 constexpr int ENC_EPI_BIAS = 0, ENC_EPI_GELU = 1, ENC_EPI_RESIDUAL = 2;
@@ -85,41 +84,53 @@ __device__ __forceinline__ void enc_ln_row(const h8 (&v)[NCH], const _Float16* g
     }
 }
 
-// NTB 16-token blocks (1, 2), KS = K / 512 (1, 2, 4, 8: a wave's slice of K is KS k-steps of 32), FPB output features per workgroup.
-// grid N / FPB, 1024 threads. Dynamic LDS: slabs NTB * 16 KiB | LNPRO: the LayerNorm'd activations [NTB*16][K] fp16, 16-byte chunk
-// ci of row r in slot ci ^ (r & 15) (a fragment read takes the same chunk of 16 rows: 16 different bank slots) | 12 KiB scratch the
-// weight prefetch lands in.
-template <int NTB, int KS, int FPB, bool LNPRO, int EPI>
+// NTB 16-token blocks (1, 2); K = NPH phases of KC = KCS * 512 input features (512 | 1024 | 2 x 1024 | 4 x 1024); FPB output features
+// per workgroup. grid N / FPB, 1024 threads = 16 waves; in every phase wave w multiplies k's [64 w .. 64 w + 63] (KCS = 2) of the phase.
+// The activation block of a phase, [NTB*16][KC], is read ONCE per workgroup in whole rows (128-byte lines; round 4's first version took
+// its B fragments straight from global memory as 16 rows x 64 bytes per instruction: twice the work for the CU's load path, 13 us for
+// FFN-down's 256 KB) into an LDS image — LayerNorm'd on the way for LNPRO — while the next phase's rows are already on their way to
+// registers; 16-byte chunk ci of row r sits in slot ci ^ (r & 15) (a fragment read takes the same chunk of 16 rows: 16 bank slots).
+// Dynamic LDS: slabs NTB * 16 KiB | image NTB * 16 * KC * 2 bytes.
+template <int NTB, int KCS, int NPH, int FPB, bool LNPRO, int EPI>
 __global__ __launch_bounds__(1024) void k_enc_stage(const EncStage a) {
     extern __shared__ __attribute__((aligned(16))) char st_smem[];
-    constexpr int K = KS * 512, KQ = KS * 32;
+    static_assert(!LNPRO || NPH == 1, "the LayerNorm prologue needs whole rows in one phase");
+    constexpr int KC = KCS * 512, K = KC * NPH, KQ = KCS * 32;
     constexpr int SLAB_BYTES = NTB * 16384;
-    constexpr int IMG_BYTES = LNPRO ? NTB * 16 * K * 2 : 0;
     float* slab = reinterpret_cast<float*>(st_smem);   // [16 waves][NTB][4][64]
+    _Float16* img = reinterpret_cast<_Float16*>(st_smem + SLAB_BYTES);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * FPB;
     const int T = a.T;
 
-    // the weights first: they depend on nothing this launch or the one before it computes
+    // the weights first: they depend on nothing this launch or the one before it computes. All of them in flight at once.
     const _Float16* wp = a.w + (int64_t)(n0 + (l15 & (FPB - 1))) * K + wave * KQ + lq * 8;
-    half8 A[KS];
+    half8 A[NPH][KCS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) A[s] = *reinterpret_cast<const half8*>(wp + s * 32);
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+        for (int s = 0; s < KCS; ++s) A[ph][s] = *reinterpret_cast<const half8*>(wp + ph * KC + s * 32);
 
-    half8 B[NTB][KS];
-    if constexpr (!LNPRO) {
+    // this wave's rows of the activation block: wave + 16 i
+    const _Float16* xr[NTB];
 #pragma unroll
-        for (int tb = 0; tb < NTB; ++tb) {
-            const int t = tb * 16 + l15;
-            const int tt = t < T ? t : T - 1;
-            const int64_t row = a.x_rows ? a.x_rows[tt] : (int64_t)tt;
-            const _Float16* xp = a.x + row * K + wave * KQ + lq * 8;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) B[tb][s] = *reinterpret_cast<const half8*>(xp + s * 32);
-        }
+    for (int i = 0; i < NTB; ++i) {
+        const int r = wave + i * 16;
+        const int64_t row = (!LNPRO && a.x_rows && r < T) ? a.x_rows[r] : (int64_t)r;
+        xr[i] = a.x + row * K + lane * 8;
     }
+    h8 raw[NTB][KCS];
+    auto load_phase = [&](int ph) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NTB; ++i)
+            if (wave + i * 16 < T) {
+#pragma unroll
+                for (int c = 0; c < KCS; ++c) raw[i][c] = *reinterpret_cast<const h8*>(xr[i] + ph * KC + c * 512);
+            }
+    };
+    load_phase(0);
     // what the epilogue's threads will want (waves 0..3: accumulator register r = wave of every lane), requested now
     const int f_loc = lq * 4 + wave;                        // feature inside the MFMA tile's 16 rows
     const bool f_ok = wave < 4 && f_loc < FPB;
@@ -138,50 +149,54 @@ __global__ __launch_bounds__(1024) void k_enc_stage(const EncStage a) {
         }
     }
 
-    if constexpr (LNPRO) {
-        _Float16* img = reinterpret_cast<_Float16*>(st_smem + SLAB_BYTES);
-#pragma unroll
-        for (int i = 0; i < NTB; ++i) {
-            const int r = wave + i * 16;                    // this wave's row of the block
-            h8 y[KS];
-            if (r < T) {
-                h8 v[KS];
-#pragma unroll
-                for (int c = 0; c < KS; ++c) v[c] = *reinterpret_cast<const h8*>(a.x + (int64_t)r * K + c * 512 + lane * 8);
-                enc_ln_row<KS>(v, a.gamma, a.beta, a.eps, lane, y);
-                if (a.y_out && (r % (int)gridDim.x) == (int)blockIdx.x) {
-#pragma unroll
-                    for (int c = 0; c < KS; ++c) *reinterpret_cast<h8*>(a.y_out + (int64_t)r * K + c * 512 + lane * 8) = y[c];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < KS; ++c)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) y[c][e] = (_Float16)0.f;
-            }
-#pragma unroll
-            for (int c = 0; c < KS; ++c) {
-                const int ci = c * 64 + lane;
-                *reinterpret_cast<h8*>(img + r * K + ((ci ^ (r & 15)) * 8)) = y[c];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tb = 0; tb < NTB; ++tb)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int ci = wave * (KQ / 8) + s * 4 + lq;
-                B[tb][s] = *reinterpret_cast<const half8*>(img + (tb * 16 + l15) * K + ((ci ^ l15) * 8));
-            }
-    }
-
     f32x4 acc[NTB];
 #pragma unroll
     for (int tb = 0; tb < NTB; ++tb) acc[tb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+    for (int ph = 0; ph < NPH; ++ph) {
 #pragma unroll
-        for (int tb = 0; tb < NTB; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s], B[tb][s], acc[tb], 0, 0, 0);
+        for (int i = 0; i < NTB; ++i) {
+            const int r = wave + i * 16;
+            h8 y[KCS];
+            if (r < T) {
+                if constexpr (LNPRO) {
+                    enc_ln_row<KCS>(raw[i], a.gamma, a.beta, a.eps, lane, y);
+                    if (a.y_out && (r % (int)gridDim.x) == (int)blockIdx.x) {
+#pragma unroll
+                        for (int c = 0; c < KCS; ++c) *reinterpret_cast<h8*>(a.y_out + (int64_t)r * K + c * 512 + lane * 8) = y[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < KCS; ++c) y[c] = raw[i][c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < KCS; ++c)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[c][e] = (_Float16)0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < KCS; ++c) {
+                const int ci = c * 64 + lane;
+                *reinterpret_cast<h8*>(img + r * KC + ((ci ^ (r & 15)) * 8)) = y[c];
+            }
+        }
+        __syncthreads();
+        if (ph + 1 < NPH) load_phase(ph + 1);      // the next phase's rows travel while this one is multiplied
+        half8 B[NTB][KCS];
+#pragma unroll
+        for (int tb = 0; tb < NTB; ++tb)
+#pragma unroll
+            for (int s = 0; s < KCS; ++s) {
+                const int ci = wave * (KQ / 8) + s * 4 + lq;
+                B[tb][s] = *reinterpret_cast<const half8*>(img + (tb * 16 + l15) * KC + ((ci ^ l15) * 8));
+            }
+#pragma unroll
+        for (int s = 0; s < KCS; ++s)
+#pragma unroll
+            for (int tb = 0; tb < NTB; ++tb) acc[tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[ph][s], B[tb][s], acc[tb], 0, 0, 0);
+        if (ph + 1 < NPH) __syncthreads();          // every fragment of this phase is in registers: the image may be overwritten
+    }
 
     // D[feature = lq * 4 + r][token = l15]: park the partial tile; waves 0..3 add the sixteen in wave order
 #pragma unroll
@@ -189,20 +204,6 @@ __global__ __launch_bounds__(1024) void k_enc_stage(const EncStage a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab[((wave * NTB + tb) * 4 + r) * 64 + lane] = acc[tb][r];
     __syncthreads();
-    if (wave >= 4) {
-        // nothing left to do for these waves: touch this workgroup's share of the next stage's weights. LDS-DMA (no registers, the
-        // data lands in a scratch slot nobody reads); the wave stays until its pieces have landed — its LDS must not be handed to
-        // another workgroup with writes still on their way.
-        if (a.pf_bytes) {
-            char* dst = st_smem + SLAB_BYTES + IMG_BYTES + (wave - 4) * 1024;
-            const uint32_t stride = gridDim.x * 12u * 1024u;
-            for (uint32_t off = (blockIdx.x * 12u + (uint32_t)(wave - 4)) * 1024u; off < a.pf_bytes; off += stride)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.pf + off + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        return;
-    }
     if (!f_ok) return;
 #pragma unroll
     for (int tb = 0; tb < NTB; ++tb) {

@@ -144,6 +144,7 @@ struct rdx_index {
     int split_boot = 1;      // option: k_boot (K loop split over the waves) for the threshold bootstrap of small launches
     int fuse_finish = 1;     // option: the end-of-search work runs in the last block of the search's last kernel (0: its own launch k_finish)
     int spec_tau = 1;        // option: speculative scan threshold (rank < k of the sample, verified by k_refine)
+    int spread_boot = 1;     // option: the threshold sample is every div-th 32-row block instead of every div-th 256-row tile (B > 64)
     int spec_backoff = 0;    // searches left during which the provable threshold is used (set when a speculation failed)
     double xw[8] = {1, 1, 1, 1, 1, 1, 1, 1};   // relative speed of the XCDs as the last main scans showed it (sum 8)
     unsigned long long wg_times[1024] = {};    // start/end stamps of the last main scan's workgroups (host copy)
@@ -377,6 +378,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "split_boot") h->split_boot = value != 0;
     else if (n == "small_scan") h->small_scan = value != 0;
     else if (n == "half_boot") h->half_boot = value != 0;
+    else if (n == "spread_boot") h->spread_boot = value != 0;
     else if (n == "spec_tau") {
         h->spec_tau = value != 0;
         h->spec_backoff = 0;
@@ -655,6 +657,21 @@ extern "C" int rdx_enc_attention_f16(int device, const void* qkv, const int32_t*
     return RDX_OK;
 }
 
+extern "C" int rdx_enc_attention_mfma_f16(int device, const void* qkv, const int32_t* query_blocks, int n_blocks, int heads, int head_dim,
+                                          float scale, void* ctx, void* stream) {
+    if (n_blocks < 0 || heads < 1 || heads > 65535) return fail(RDX_ERR_INVALID, "rdx_enc_attention_mfma_f16: bad shape");
+    if (head_dim != ENC_HEAD_DIM) return fail(RDX_ERR_INVALID, "rdx_enc_attention_mfma_f16: head_dim must be 64");
+    if (n_blocks == 0) return RDX_OK;
+    if (!qkv || !query_blocks || !ctx) return fail(RDX_ERR_INVALID, "rdx_enc_attention_mfma_f16: null pointer");
+    if (((uintptr_t)qkv | (uintptr_t)ctx | (uintptr_t)query_blocks) & 15) return fail(RDX_ERR_INVALID, "rdx_enc_attention_mfma_f16: pointers must be 16-byte aligned");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_attention_mfma_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_enc_attention_mfma, dim3((unsigned)n_blocks, (unsigned)heads), dim3(256), 0, (hipStream_t)stream, (const _Float16*)qkv, query_blocks, heads,
+                       scale * 1.4426950408889634f, (_Float16*)ctx);
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
 template <bool GELU>
 static void launch_linear_small(int ntb, dim3 grid, hipStream_t st, const _Float16* x, const _Float16* w, const _Float16* b, int T, int N, int K,
                                 _Float16* out) {
@@ -730,30 +747,30 @@ static int enc_dynamic_lds(int device, const void* func, size_t bytes) {
     return RDX_OK;
 }
 
-template <int NTB, int KS, int FPB, bool LNPRO, int EPI>
+template <int NTB, int KCS, int NPH, int FPB, bool LNPRO, int EPI>
 static int launch_enc_stage(int device, const EncStage& a, hipStream_t st) {
-    const size_t lds = (size_t)NTB * 16384 + (LNPRO ? (size_t)NTB * 16 * KS * 512 * 2 : 0) + 12288;
-    auto* fn = k_enc_stage<NTB, KS, FPB, LNPRO, EPI>;
+    const size_t lds = (size_t)NTB * 16384 + (size_t)NTB * 16 * KCS * 512 * 2;
+    auto* fn = k_enc_stage<NTB, KCS, NPH, FPB, LNPRO, EPI>;
     RDX_TRY(enc_dynamic_lds(device, (const void*)fn, lds));
     hipLaunchKernelGGL(fn, dim3((unsigned)(a.N / FPB)), dim3(1024), lds, st, a);
     HIP_TRY(hipGetLastError());
     return RDX_OK;
 }
 
-template <int NTB, int KS>
+template <int NTB, int KCS, int NPH>
 static int dispatch_enc_stage(int device, const EncStage& a, bool lnpro, int epi, int fpb, hipStream_t st) {
     if (lnpro) {
-        if constexpr (KS <= 2) {
-            if (epi == ENC_EPI_BIAS) return launch_enc_stage<NTB, KS, 16, true, ENC_EPI_BIAS>(device, a, st);
-            if (epi == ENC_EPI_GELU) return launch_enc_stage<NTB, KS, 16, true, ENC_EPI_GELU>(device, a, st);
+        if constexpr (NPH == 1) {
+            if (epi == ENC_EPI_BIAS) return launch_enc_stage<NTB, KCS, 1, 16, true, ENC_EPI_BIAS>(device, a, st);
+            if (epi == ENC_EPI_GELU) return launch_enc_stage<NTB, KCS, 1, 16, true, ENC_EPI_GELU>(device, a, st);
         }
         return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: the LayerNorm prologue takes n_in 512 or 1024 and epilogue 0 or 1");
     }
 #define RDX_ENC_PLAIN(F)                                                                                                   \
     if (fpb == F) {                                                                                                        \
-        if (epi == ENC_EPI_BIAS) return launch_enc_stage<NTB, KS, F, false, ENC_EPI_BIAS>(device, a, st);                  \
-        if (epi == ENC_EPI_GELU) return launch_enc_stage<NTB, KS, F, false, ENC_EPI_GELU>(device, a, st);                  \
-        return launch_enc_stage<NTB, KS, F, false, ENC_EPI_RESIDUAL>(device, a, st);                                        \
+        if (epi == ENC_EPI_BIAS) return launch_enc_stage<NTB, KCS, NPH, F, false, ENC_EPI_BIAS>(device, a, st);            \
+        if (epi == ENC_EPI_GELU) return launch_enc_stage<NTB, KCS, NPH, F, false, ENC_EPI_GELU>(device, a, st);            \
+        return launch_enc_stage<NTB, KCS, NPH, F, false, ENC_EPI_RESIDUAL>(device, a, st);                                  \
     }
     RDX_ENC_PLAIN(16)
     RDX_ENC_PLAIN(8)
@@ -764,8 +781,7 @@ static int dispatch_enc_stage(int device, const EncStage& a, bool lnpro, int epi
 
 extern "C" int rdx_enc_stage_f16(int device, const void* x, const int64_t* x_rows, const void* ln_gamma, const void* ln_beta, float ln_eps,
                                  void* y_out, const void* w, const void* bias, const void* res, int n_tokens, int n_out, int n_in,
-                                 int epilogue, int features_per_workgroup, const void* prefetch, int64_t prefetch_bytes, void* out,
-                                 void* stream) {
+                                 int epilogue, int features_per_workgroup, void* out, void* stream) {
     if (n_tokens < 0 || n_tokens > 32) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: at most 32 tokens");
     if (n_in != 512 && n_in != 1024 && n_in != 2048 && n_in != 4096) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: n_in must be 512, 1024, 2048 or 4096");
     if (epilogue < 0 || epilogue > 2) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: epilogue is 0 (bias), 1 (bias + erf GELU) or 2 (bias + residual)");
@@ -775,10 +791,9 @@ extern "C" int rdx_enc_stage_f16(int device, const void* x, const int64_t* x_row
     if (lnpro && (!ln_beta || x_rows)) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: the LayerNorm prologue needs gamma and beta and takes no row list");
     if (lnpro && fpb != 16) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: the LayerNorm prologue runs with 16 features per workgroup");
     if (epilogue == 2 && !res) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: epilogue 2 needs the residual");
-    if (prefetch_bytes < 0 || (prefetch_bytes && !prefetch)) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: bad prefetch range");
     if (n_tokens == 0) return RDX_OK;
     if (!x || !w || !bias || !out) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: null pointer");
-    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)y_out | (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)prefetch) & 15)
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)y_out | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15)
         return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: pointers must be 16-byte aligned");
     if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_stage_f16: device out of range");
     HIP_TRY(hipSetDevice(device));
@@ -795,20 +810,17 @@ extern "C" int rdx_enc_stage_f16(int device, const void* x, const int64_t* x_row
     a.out = (_Float16*)out;
     a.T = n_tokens;
     a.N = n_out;
-    a.pf = (const char*)prefetch;
-    a.pf_bytes = (uint32_t)std::min<int64_t>(prefetch_bytes, (int64_t)1 << 30) & ~1023u;
     hipStream_t st = (hipStream_t)stream;
-    const int ks = n_in / 512;
-#define RDX_ENC_KS(NTB)                                                                \
-    switch (ks) {                                                                      \
-        case 1: return dispatch_enc_stage<NTB, 1>(device, a, lnpro, epilogue, fpb, st); \
-        case 2: return dispatch_enc_stage<NTB, 2>(device, a, lnpro, epilogue, fpb, st); \
-        case 4: return dispatch_enc_stage<NTB, 4>(device, a, lnpro, epilogue, fpb, st); \
-        default: return dispatch_enc_stage<NTB, 8>(device, a, lnpro, epilogue, fpb, st); \
+#define RDX_ENC_K(NTB)                                                                         \
+    switch (n_in) {                                                                            \
+        case 512: return dispatch_enc_stage<NTB, 1, 1>(device, a, lnpro, epilogue, fpb, st);   \
+        case 1024: return dispatch_enc_stage<NTB, 2, 1>(device, a, lnpro, epilogue, fpb, st);  \
+        case 2048: return dispatch_enc_stage<NTB, 2, 2>(device, a, lnpro, epilogue, fpb, st);  \
+        default: return dispatch_enc_stage<NTB, 2, 4>(device, a, lnpro, epilogue, fpb, st);    \
     }
-    if (n_tokens <= 16) { RDX_ENC_KS(1) }
-    RDX_ENC_KS(2)
-#undef RDX_ENC_KS
+    if (n_tokens <= 16) { RDX_ENC_K(1) }
+    RDX_ENC_K(2)
+#undef RDX_ENC_K
 }
 
 extern "C" int rdx_enc_attention_small_f16(int device, const void* qkv, const int32_t* tok_first, int n_tokens, int heads, int head_dim,
@@ -1252,12 +1264,17 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
                 n_sched = (n_tiles + div - 1) / div;
             }
         }
+        // The sample as every div-th 32-ROW BLOCK (option "spread_boot", default 1) instead of every div-th 256-row tile: the same number
+        // of rows, eight times finer. Wave w of virtual tile j takes block (8 j + w) * div; the last virtual tile ends inside the corpus.
+        const int64_t n_blocks32 = (h->rows + 31) / 32;
+        const int64_t n_virtual = ((n_blocks32 - 1) / div + 1) / 8;
+        const bool spread = h->spread_boot && n_virtual >= 1;
+        if (spread) n_sched = n_virtual;
         sample_rows = n_sched * 256;
         int n_sets_used = (int)std::min<int64_t>(ns_b, n_sched) * SETS_PER_STREAM;
         // Small launches (<= 64 queries and a sample of at most four 32-row blocks per CU): the split-K bootstrap k_boot — one
         // 32-row block per workgroup, the k-steps dealt to the waves — instead of a few whole tiles of 16 dependent k-steps on
         // a few CUs (scan_kernel.hpp K2b). Whole rounds of the CUs when more than one.
-        const int64_t n_blocks32 = (h->rows + 31) / 32;
         int64_t boot_units = std::min<int64_t>(n_blocks32, n_sched * 8);
         if (boot_units > h->n_cu) boot_units = boot_units / h->n_cu * h->n_cu;
         const bool use_boot = h->split_boot && bn == BOOT_BN && nqt == 1 && boot_units <= 4 * (int64_t)h->n_cu;
@@ -1324,6 +1341,13 @@ static int search_chunk_impl(rdx_index* h, const float* d_queries, int64_t nq, i
         } else {
             ScanParams pb = p;
             pb.tile_stride = div;
+            pb.span = TILE_ROWS;
+            if (spread) {   // wave w of sampled entry j: block (8 j + w) * div (scan_kernel.hpp ScanParams::wave_off)
+                pb.wave_off = (int64_t)(div - 1) * h->ksteps * 4096;
+                pb.row_off = (div - 1) * 32;
+                pb.span = (7 * div + 1) * 32;
+                pb.n_tiles = (n_virtual - 1) * (int64_t)div + 1;   // ceil(n_tiles / div) = n_virtual entries: the last block lies inside the corpus
+            }
             pb.nqt = nqt_b;
             pb.n_sets = n_sets_b;
             pb.sib = nullptr;
@@ -1796,6 +1820,11 @@ extern "C" int rdx_search_masked(rdx_index* h, const float* queries, int64_t nq,
     return search_impl(h, queries, nq, k, mask ? mask->words.as<uint32_t>() : nullptr, true, out_score, out_row, out_count, space, stream);
 }
 
+#ifdef RDX_REFINE_STAMPS
+extern "C" int rdx_debug_refine_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(rdx::g_refine_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
 #ifdef RDX_SELECT_STAMPS
 extern "C" int rdx_debug_select_stamps(unsigned long long* out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(rdx::g_select_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;

@@ -128,6 +128,13 @@ __device__ __forceinline__ void finish_if_last(const FinishArgs& f) {
 //   P = {coarse >= c_k - 2E} contains the exact top-k; P is re-scored exactly from the fp32 master copy (fp64 lane-order
 //   sum, oracle/rdx_oracle.c) and ranked (score desc, row asc).
 //   A segment, list or P overflow cannot be answered here: the query is flagged for the exact full scan.
+#ifdef RDX_REFINE_STAMPS   // developer build (tools/refine_stamps.py): where k_refine spends its time (block 0's phases, 100 MHz wall clock)
+__device__ unsigned long long g_refine_stamps[16];
+#define RDX_RSTAMP(i) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) g_refine_stamps[i] = wall_clock64(); } while (0)
+#else
+#define RDX_RSTAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,
                                                 int n_streams, uint32_t capw, uint32_t list_cap, int k, float two_e,
                                                 const float* __restrict__ qhat, MasterView master, int dim,
@@ -148,6 +155,7 @@ __device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, con
     int64_t* o_r = out_row + (int64_t)q * k;
     if (threadIdx.x == 0) overflow = 0;
     __syncthreads();
+    RDX_RSTAMP(0);
     // segment sizes -> exclusive prefix. Wave 0 scans them 64 at a time with shuffles (n_streams <= 512: at most 8 rounds; the
     // serial loop this replaces was 3-5 us of the kernel at 256 streams)
     for (int w = threadIdx.x; w < n_streams; w += blockDim.x) {
@@ -174,6 +182,7 @@ __device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, con
     }
     __syncthreads();
     const uint32_t m = seg_off[n_streams];
+    RDX_RSTAMP(1);
     if (threadIdx.x == 0) atomicAdd(&ctr->emitted, (unsigned long long)m);
     if (overflow || m > list_cap) {
         if (threadIdx.x == 0) exact_list[atomicAdd(&ctr->n_exact, 1)] = q;
@@ -190,10 +199,12 @@ __device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, con
         for (uint32_t i = a; i < b; ++i) list[i] = seg[i - a];
     }
     __syncthreads();
+    RDX_RSTAMP(2);
     const int64_t kk = (uint32_t)k < m ? k : m;
     int64_t n_gt;
     const uint32_t kth = block_kth_largest([&](int64_t i) { return f2key(__uint_as_float(list[i].x)); }, m, kk, hist, bc, &n_gt);
     const float t2 = key2f(kth) - two_e;
+    RDX_RSTAMP(3);
     // Verification of the scan's threshold T (score units). The hits are exactly the allowed rows with coarse >= T. The k best of
     // them have exact >= c_k - E, so the exact k-th best of the corpus is >= c_k - E and every true top-k row has coarse >=
     // c_k - 2E: all of those were emitted iff c_k - 2E >= T (and k hits exist at all). A threshold taken from k sampled rows
@@ -219,11 +230,52 @@ __device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, con
     }
     __syncthreads();
     const int p = n_p;
+    if (threadIdx.x == 0) atomicAdd(&ctr->rescored, (unsigned long long)p);
     if (p > REFINE_PMAX) {
-        if (threadIdx.x == 0) exact_list[atomicAdd(&ctr->n_exact, 1)] = q;
+        // More rows inside the 2E band than the ranking arrays hold: near-duplicate rows stored together (a document's chunks: their
+        // scores lie closer together than the coarse pass can tell apart, so the band holds hundreds to thousands of them). Until
+        // round 4 such a query paid the exact full scan of the WHOLE corpus (7 ms per 4 queries at 10 M rows: an embedding-like corpus
+        // ran at 2 % of the N(0,1) corpus' speed). The band is small next to the corpus: every member is re-scored exactly in place
+        // (its exact score over its coarse one in the list; the others become -inf), the k-th largest exact score is found by the
+        // radix select, and only what reaches it is ranked.
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+        const float4* q4 = reinterpret_cast<const float4*>(qhat + (int64_t)q * dim);
+        const int n4 = dim >> 2;
+        for (uint32_t i = wave; i < m; i += nw) {          // (i is wave-uniform: no divergence around the row's loads)
+            const uint2 e = list[i];
+            float sx = -INFINITY;
+            if (__uint_as_float(e.x) >= t2) sx = exact_score(master_row(master, (int64_t)e.y, dim), q4, n4, lane);
+            if (lane == 0) list[i].x = __float_as_uint(sx);
+        }
+        __syncthreads();
+        const int64_t kk2 = k < p ? k : p;
+        int64_t n_gt2;
+        const uint32_t kth2 = block_kth_largest([&](int64_t i) { return f2key(__uint_as_float(list[i].x)); }, m, kk2, hist, bc, &n_gt2);
+        if (threadIdx.x == 0) n_p = 0;
+        __syncthreads();
+        // everything above the k-th key, and EVERY entry equal to it (identical rows tie: the ranking below orders them by row id)
+        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+            const uint2 e = list[i];
+            if (f2key(__uint_as_float(e.x)) >= kth2) {
+                const int pos = atomicAdd(&n_p, 1);
+                if (pos < REFINE_PMAX) {
+                    s_s[pos] = __uint_as_float(e.x);
+                    s_r[pos] = (int64_t)e.y;
+                }
+            }
+        }
+        __syncthreads();
+        const int p2 = n_p;
+        if (p2 > REFINE_PMAX) {                              // > 1024 - k rows IDENTICAL to the k-th: only the exact scan orders those
+            if (threadIdx.x == 0) exact_list[atomicAdd(&ctr->n_exact, 1)] = q;
+            return;
+        }
+        for (int i = threadIdx.x; i < p2; i += blockDim.x) s_r[i] = row_map ? row_map[s_r[i]] : s_r[i] + row_base;
+        __syncthreads();
+        rank_and_write(s_s, s_r, p2, k, o_s, o_r, out_count + q);
         return;
     }
-    if (threadIdx.x == 0) atomicAdd(&ctr->rescored, (unsigned long long)p);
+    RDX_RSTAMP(4);
     // exact re-score: one wave per candidate row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4* q4 = reinterpret_cast<const float4*>(qhat + (int64_t)q * dim);
@@ -275,10 +327,12 @@ __device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, con
         }
     }
     __syncthreads();
+    RDX_RSTAMP(5);
     // local -> returned row id: + row_base, or through the shard's (strictly increasing) row id map
     for (int i = threadIdx.x; i < p; i += blockDim.x) s_r[i] = row_map ? row_map[s_r[i]] : s_r[i] + row_base;
     __syncthreads();
     rank_and_write(s_s, s_r, p, k, o_s, o_r, out_count + q);
+    RDX_RSTAMP(6);
 }
 
 __global__ __launch_bounds__(1024) void k_refine(const uint2* __restrict__ cand, const uint32_t* __restrict__ cntw,

@@ -106,6 +106,14 @@ struct ScanParams {
     int64_t rows;              // valid corpus rows
     int64_t n_tiles;           // ceil(rows / 256)
     int tile_stride;           // 1 (main) or sample_div (bootstrap): tiles 0, stride, 2*stride, ...
+    // EPI_SETMAX, option "spread_boot": the sample is every S-th 32-ROW BLOCK instead of every S-th 256-row tile — wave w of schedule
+    // entry j scans block (8 j + w) * S = the tile formula's block j * S * 8 + w PLUS w * (S - 1): one per-wave constant on the scan
+    // copy's base (wave_off = (S - 1) * bytes of a block) and on the row number (row_off = (S - 1) * 32); span = rows from a tile's
+    // first row to the end of its last wave's block (256, or (7 S + 1) * 32). The same number of sampled rows, eight times finer: a
+    // run of similar rows stored together (a document's chunks) that fell between two sampled tiles is met by several sampled
+    // blocks. The host bounds n_tiles so that every block lies inside the corpus. Tile sample: 0, 0, 256.
+    int64_t wave_off;
+    int row_off, span;
     int nqt;                   // query tiles of BN queries
     int nq_pad;                // queries padded to 256
     const uint32_t* allow;     // NULL or row bitmap
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     int oob_seen = 0;                              // RDX_CHECK_BOUNDS builds only
     const int64_t rb_bytes = (int64_t)KS * 4096;   // bytes of one 32-row block in the scan copy
     const uint32_t lane16 = (uint32_t)lane * 16;
+    const char* const shadow_w = reinterpret_cast<const char*>(p.shadow) + (EPI == EPI_SETMAX ? wave * p.wave_off : (int64_t)0);   // (block sample: see ScanParams)
     auto a_src = [&](int it_i, int ks_i) __attribute__((always_inline)) -> const char* {
         const int64_t tile = (int64_t)sched_of(it_i) * p.tile_stride;
 #ifdef RDX_CHECK_BOUNDS
@@ -265,13 +274,13 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
         // scan copy; an address outside is remembered (reported once, when the workgroup ends) and replaced, so the run ends
         // with an error code instead of a GPU fault. Branch-free: the address stays wave-uniform scalar arithmetic.
         {
-            const int64_t off = (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096;
+            const int64_t off = (tile * 8 + wave) * rb_bytes + (int64_t)ks_i * 4096 + (EPI == EPI_SETMAX ? wave * p.wave_off : (int64_t)0);
             const bool bad = off < 0 || off + 4096 > p.shadow_bytes;
             oob_seen |= bad ? 1 : 0;
             return reinterpret_cast<const char*>(p.shadow) + (bad ? (int64_t)0 : off);
         }
 #endif
-        return reinterpret_cast<const char*>(p.shadow) + (tile * 8 + (DBLA ? (wave & 3) * 2 : wave)) * rb_bytes + (int64_t)ks_i * 4096;   // wave-uniform
+        return shadow_w + (tile * 8 + (DBLA ? (wave & 3) * 2 : wave)) * rb_bytes + (int64_t)ks_i * 4096;   // wave-uniform
     };
 
     // v_mfma_f32_16x16x32_f16: the wave's 32 rows are two 16-row blocks m, the queries NB16 blocks of 16; C layout
@@ -308,8 +317,8 @@ __global__ __launch_bounds__(512) void k_scan(const ScanParams p) {
     // which rows of this wave's 32-row block of schedule entry it_done may be used (ragged last tile, `where` bitmap)
     auto tile_rows = [&](int it_done, int64_t& row_b, uint32_t& okbits, bool& filt) __attribute__((always_inline)) {
         const int64_t tile = (int64_t)sched_of(it_done) * p.tile_stride;
-        row_b = tile * TILE_ROWS + wave * 32;                  // first row of this wave's 32-row block
-        const bool ragged = (tile + 1) * TILE_ROWS > p.rows;   // tile holds padding rows
+        row_b = tile * TILE_ROWS + wave * (EPI == EPI_SETMAX ? 32 + p.row_off : 32);   // first row of this wave's 32-row block
+        const bool ragged = tile * TILE_ROWS + (EPI == EPI_SETMAX ? p.span : TILE_ROWS) > p.rows;   // tile holds padding rows
         okbits = 0xffffffffu;                                  // bit i: row row_b+i may be used
         if (ragged) {
             const int64_t left = p.rows - row_b;

@@ -129,9 +129,9 @@ class _PackedEncoder:
             self.small_stage = self.hidden in (512, 1024) and inter0.weight.shape[0] in (512, 1024, 2048, 4096)
             self.stage_fpb_o = int(os.environ.get("RDX_ENC_FPB_O", self.STAGE_FPB_O))
             self.stage_fpb_f2 = int(os.environ.get("RDX_ENC_FPB_F2", self.STAGE_FPB_F2))
-            self.stage_prefetch = os.environ.get("RDX_ENC_PREFETCH", "1" if self.STAGE_PREFETCH else "0") != "0"
 
-    FUSED_MAX_TOKENS = 64
+    FUSED_MAX_TOKENS = 64       # up to here the VALU attention kernel (written for questions); beyond, the MFMA kernel (long_attention)
+    long_attention = os.environ.get("RDX_ENC_LONG_ATTN", "mfma") != "torch"   # developer: "torch" = scatter -> SDPA -> gather for texts beyond 64 tokens
 
     def _add_ln(self, a: torch.Tensor, b: torch.Tensor, ln) -> torch.Tensor:
         out = torch.empty_like(a)
@@ -155,9 +155,16 @@ class _PackedEncoder:
             raise RuntimeError("rdx_enc_linear_small_f16: " + self._last_error())
         return out
 
-    def _attention(self, qkv: torch.Tensor, tok_first: torch.Tensor, tok_len: torch.Tensor, max_len: int) -> torch.Tensor:
+    def _attention(self, qkv: torch.Tensor, tok_first: torch.Tensor, tok_len: torch.Tensor, max_len: int, qb=None) -> torch.Tensor:
         T = qkv.shape[0]
         ctx = torch.empty((T, self.hidden), dtype=qkv.dtype, device=qkv.device)
+        if qb is not None:                # texts beyond FUSED_MAX_TOKENS (the corpus side): the flash-style MFMA kernel over 64-query blocks
+            rc = self._lib.rdx_enc_attention_mfma_f16(qkv.device.index or 0, qkv.data_ptr(), qb.data_ptr(), int(qb.shape[0]), self.heads,
+                                                      self.hidden // self.heads, (self.hidden // self.heads) ** -0.5, ctx.data_ptr(),
+                                                      torch.cuda.current_stream(qkv.device).cuda_stream)
+            if rc:
+                raise RuntimeError("rdx_enc_attention_mfma_f16: " + self._last_error())
+            return ctx
         rc = self._lib.rdx_enc_attention_f16(qkv.device.index or 0, qkv.data_ptr(), tok_first.data_ptr(), tok_len.data_ptr(), T, self.heads,
                                              self.hidden // self.heads, (self.hidden // self.heads) ** -0.5, int(max_len), ctx.data_ptr(),
                                              torch.cuda.current_stream(qkv.device).cuda_stream)
@@ -176,27 +183,28 @@ class _PackedEncoder:
     # nothing on the GPU, 3 ms of host time; production batches rarely repeat a token count). False: never. At most MAX_GRAPHS shapes
     # are kept (least recently used out).
     graphs = "auto"
+    large_graphs = os.environ.get("RDX_ENC_LARGE_GRAPHS", "1") != "0"   # canonical-shape graphs for large question batches too (cls())
+    LARGE_TOKEN_GRANULE = 1024
+    MAX_LARGE_GRAPHS = 3
     MAX_GRAPHS = 64
     SMALL_TEXTS = 8
     SMALL_TOKEN_GRANULE = 32
 
     # One question (at most STAGE_TOKENS packed tokens, padded to 16 or 32): five launches per layer, csrc/enc_small.hpp. The output
     # projection and FFN-down have 1024 features: with 16 per workgroup they would occupy 64 CUs, so their workgroups take 8 / 4 rows of
-    # the MFMA tile (developer knobs RDX_ENC_FPB_O / RDX_ENC_FPB_F2 / RDX_ENC_PREFETCH; measured values in DESIGN.md §10).
+    # the MFMA tile (developer knobs RDX_ENC_FPB_O / RDX_ENC_FPB_F2; measured values in DESIGN.md §10).
     STAGE_TOKENS = 32
     STAGE_FPB_O = 8
-    STAGE_FPB_F2 = 4
-    STAGE_PREFETCH = False   # measured (profiles/r04/enc_small_sweep.txt): touching the next stage's weights from the idle waves makes every kernel wait for those loads: +0.08 ms per question
+    STAGE_FPB_F2 = 8
 
-    def _stage(self, x, w, b, T, ln=None, y_out=None, res=None, rows=None, epi=0, fpb=0, pf=None):
+    def _stage(self, x, w, b, T, ln=None, y_out=None, res=None, rows=None, epi=0, fpb=0):
         N, K = int(w.shape[0]), int(w.shape[1])
         out = torch.empty((T, N), dtype=torch.float16, device=w.device)
-        pfb = pf.numel() * 2 if (pf is not None and self.stage_prefetch) else 0
         rc = self._lib.rdx_enc_stage_f16(w.device.index or 0, x.data_ptr(), rows.data_ptr() if rows is not None else None,
                                          ln.weight.data_ptr() if ln is not None else None, ln.bias.data_ptr() if ln is not None else None,
                                          float(ln.eps) if ln is not None else 0.0, y_out.data_ptr() if y_out is not None else None,
                                          w.data_ptr(), b.data_ptr(), res.data_ptr() if res is not None else None, T, N, K, epi, fpb,
-                                         pf.data_ptr() if pfb else None, pfb, out.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream)
+                                         out.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream)
         if rc:
             raise RuntimeError("rdx_enc_stage_f16: " + self._last_error())
         return out
@@ -213,7 +221,7 @@ class _PackedEncoder:
         ln, last = self.ln, len(self.layers) - 1
         for li, (wqkv, bqkv, dense_o, ln1, inter, out, ln2) in enumerate(self.layers):
             y = torch.empty((T, H), dtype=torch.float16, device=dev)
-            qkv = self._stage(s, wqkv, bqkv, T, ln=ln, y_out=y, epi=0, pf=dense_o.weight)
+            qkv = self._stage(s, wqkv, bqkv, T, ln=ln, y_out=y, epi=0)
             ctx = torch.empty((T, H), dtype=torch.float16, device=dev)
             if lib.rdx_enc_attention_small_f16(di, qkv.data_ptr(), tok_first.data_ptr(), T, self.heads, H // self.heads,
                                                (H // self.heads) ** -0.5, ctx.data_ptr(), st):
@@ -221,19 +229,18 @@ class _PackedEncoder:
             rows = None
             if li == last:                                   # everything behind the last attention is row-wise: only the CLS rows are needed
                 rows, T = first_d, n_cls
-            s1 = self._stage(ctx, dense_o.weight, dense_o.bias, T, res=y, rows=rows, epi=2, fpb=self.stage_fpb_o, pf=inter.weight)
+            s1 = self._stage(ctx, dense_o.weight, dense_o.bias, T, res=y, rows=rows, epi=2, fpb=self.stage_fpb_o)
             y1 = torch.empty((T, H), dtype=torch.float16, device=dev)
-            f = self._stage(s1, inter.weight, inter.bias, T, ln=ln1, y_out=y1, epi=1, pf=out.weight)
-            nxt = self.layers[li + 1][0] if li < last else None
-            s = self._stage(f, out.weight, out.bias, T, res=y1, epi=2, fpb=self.stage_fpb_f2, pf=nxt)
+            f = self._stage(s1, inter.weight, inter.bias, T, ln=ln1, y_out=y1, epi=1)
+            s = self._stage(f, out.weight, out.bias, T, res=y1, epi=2, fpb=self.stage_fpb_f2)
             ln = ln2
         o = torch.empty((n_cls, H), dtype=torch.float32, device=dev)
         if lib.rdx_enc_layernorm_rows_f16(di, s.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), float(ln.eps), n_cls, H, o.data_ptr(), st):
             raise RuntimeError("rdx_enc_layernorm_rows_f16: " + self._last_error())
         return o
 
-    def _fused_forward(self, tok, pos, first_d, tok_first, tok_len, max_len: int = 0) -> torch.Tensor:
-        """the forward on packed tokens with librdx's two kernels: [T] ids / positions -> fp32 [B][hidden] CLS rows"""
+    def _fused_forward(self, tok, pos, first_d, tok_first, tok_len, max_len: int = 0, qb=None) -> torch.Tensor:
+        """the forward on packed tokens with librdx's kernels: [T] ids / positions -> fp32 [B][hidden] CLS rows"""
         if self.small_stage and tok.shape[0] <= self.STAGE_TOKENS:
             return self._small_forward(tok, pos, first_d, tok_first)
         F = torch.nn.functional
@@ -242,7 +249,7 @@ class _PackedEncoder:
         small = self.small_linear and x.shape[0] <= self.SMALL_TOKENS   # one question, a question's sub-queries: weight-streaming projections, GELU in the epilogue
         for li, (wqkv, bqkv, dense_o, ln1, inter, out, ln2) in enumerate(self.layers):
             qkv = self._linear(x, wqkv, bqkv) if small else F.linear(x, wqkv, bqkv)
-            ctx = self._attention(qkv, tok_first, tok_len, max_len)                                               # [T][H], no padding anywhere
+            ctx = self._attention(qkv, tok_first, tok_len, max_len, qb)                                           # [T][H], no padding anywhere
             if li == last:                                   # everything behind the last attention is row-wise: only the CLS rows are needed
                 ctx, x = ctx.index_select(0, first_d), x.index_select(0, first_d)
             if small:
@@ -253,8 +260,10 @@ class _PackedEncoder:
                 x = self._add_ln(out(F.gelu(inter(x))), x, ln2)
         return x.to(torch.float32)
 
-    def _replay(self, key, host: dict, to_dev, max_len: int):
-        """-> the CLS rows from a captured graph of this shape, or None (shape not captured: the caller runs eagerly)"""
+    def _replay(self, key, host: dict, to_dev, max_len: int, unpack=None):
+        """-> the CLS rows from a captured graph of this shape, or None (shape not captured: the caller runs eagerly).
+        unpack: the forward's index tensors as views of the one static buffer host["pk_blob"] is copied into"""
+        args = (lambda st: unpack(st["pk_blob"])) if unpack is not None else (lambda st: tuple(st[n] for n in self._ORDER))
         ent = self._graph.pop(key, None)
         if ent is None:
             if len(self._seen) > 4096:
@@ -272,14 +281,14 @@ class _PackedEncoder:
                 side = torch.cuda.Stream(device=dev)             # one eager run on a side stream first (library workspaces), as torch asks
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
-                    self._fused_forward(*(static[n] for n in self._ORDER), max_len)
+                    self._fused_forward(*args(static), max_len, static.get("pk_qb"))
                 torch.cuda.current_stream(dev).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
                 # thread-local capture mode: only THIS thread's calls are restricted while the capture runs — a search another
                 # thread has in flight on the same device (one shared provider and collection serve concurrent sessions, reference
                 # app.py:42-43) may allocate and synchronise as it likes
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    out = self._fused_forward(*(static[n] for n in self._ORDER), max_len)
+                    out = self._fused_forward(*args(static), max_len, static.get("pk_qb"))
             except Exception as e:                               # noqa: BLE001  (a capture that fails costs speed only: eager from now on)
                 logger.warning(f"encoder graph capture failed ({e!r}); the forward stays eager")
                 self.graphs = False
@@ -309,28 +318,74 @@ class _PackedEncoder:
         host = {"pk_tok": torch.from_numpy(np.ascontiguousarray(ids_np[row, col])), "pk_pos": torch.from_numpy(col + (self.pad + 1)),
                 "pk_first": torch.from_numpy(first)}
         H, nh = self.hidden, self.heads
-        if self.fused and int(lens.max()) <= self.FUSED_MAX_TOKENS:
+        if self.fused and (int(lens.max()) <= self.FUSED_MAX_TOKENS or self.long_attention):
             host["pk_tfirst"] = torch.from_numpy(np.repeat(first, lens).astype(np.int32))
             host["pk_tlen"] = torch.from_numpy(np.repeat(lens, lens).astype(np.int32))
             max_len = int(lens.max())
-            if self.graphs and B <= self.SMALL_TEXTS:
-                g = 16 if (self.small_stage and T <= 16) else self.SMALL_TOKEN_GRANULE   # (a question of <= 16 tokens: one token block per stage)
-                extra = -(-T // g) * g - T                       # one-token dummy texts behind the real ones
+            if max_len > self.FUSED_MAX_TOKENS:
+                # the corpus side: chunk texts of hundreds of tokens. One work unit per 64 queries of a text: {first token, length, first query}
+                nb = (lens + 63) // 64
+                tix = np.repeat(np.arange(B, dtype=np.int64), nb)
+                q0 = (np.arange(int(nb.sum()), dtype=np.int64) - np.repeat(np.cumsum(nb) - nb, nb)) * 64
+                host["pk_qb"] = torch.from_numpy(np.stack([first[tix], lens[tix], q0, np.zeros_like(q0)], axis=1).astype(np.int32))
+            if self.graphs and B <= self.SMALL_TEXTS and max_len <= self.FUSED_MAX_TOKENS:
+                # (<= 32 tokens run the stage kernels: their cost follows the activation rows a workgroup stages, so the canonical shapes
+                #  are 8, 16, 24 and 32 tokens — a typical 20-token question pays for 24 rows, not 32)
+                g = 8 if (self.small_stage and T <= self.STAGE_TOKENS) else self.SMALL_TOKEN_GRANULE
+                Tp = -(-T // g) * g                               # one-token dummy texts behind the real ones
                 lb = 16 if max_len <= 16 else (32 if max_len <= 32 else 64)
-                padded = {"pk_tok": torch.cat([host["pk_tok"], torch.full((extra,), self.pad, dtype=torch.int64)]),
-                          "pk_pos": torch.cat([host["pk_pos"], torch.full((extra,), self.pad + 1, dtype=torch.int64)]),
-                          "pk_first": torch.cat([host["pk_first"], torch.zeros(self.SMALL_TEXTS - B, dtype=torch.int64)]),
-                          "pk_tfirst": torch.cat([host["pk_tfirst"], torch.arange(T, T + extra, dtype=torch.int32)]),
-                          "pk_tlen": torch.cat([host["pk_tlen"], torch.ones(extra, dtype=torch.int32)])}
-                out = self._replay(("small", T + extra, lb), padded, to_dev, lb)
+                # the five index arrays of the canonical shape in ONE buffer: one pinned copy per question instead of five
+                # (each small copy is ~15 us of stream time: 0.07 of a 0.95 ms embed_query)
+                o1, o2, o3, o4, nb_ = 8 * Tp, 16 * Tp, 16 * Tp + 8 * self.SMALL_TEXTS, 20 * Tp + 8 * self.SMALL_TEXTS, 24 * Tp + 8 * self.SMALL_TEXTS
+                blob = np.empty(nb_, dtype=np.uint8)
+                v64, v32 = blob[:o3].view(np.int64), blob[o3:].view(np.int32)
+                v64[:T] = ids_np[row, col]
+                v64[T:Tp] = self.pad
+                v64[Tp:Tp + T] = col + (self.pad + 1)
+                v64[Tp + T:2 * Tp] = self.pad + 1
+                v64[2 * Tp:2 * Tp + B] = first
+                v64[2 * Tp + B:] = 0
+                v32[:T] = np.repeat(first, lens)
+                v32[T:Tp] = np.arange(T, Tp)
+                v32[Tp:Tp + T] = np.repeat(lens, lens)
+                v32[Tp + T:] = 1
+
+                def unpack(d):
+                    return (d[:o1].view(torch.int64), d[o1:o2].view(torch.int64), d[o2:o3].view(torch.int64), d[o3:o4].view(torch.int32),
+                            d[o4:].view(torch.int32))
+                hb = {"pk_blob": torch.from_numpy(blob)}
+                out = self._replay(("small", Tp, lb), hb, to_dev, lb, unpack)
                 if out is None:   # shape not captured yet: the SAME padded tensors eagerly, so that call 1 and the replays run identical shapes
-                    out = self._fused_forward(*(to_dev(n, padded[n]) for n in self._ORDER), lb)
+                    out = self._fused_forward(*unpack(to_dev("pk_blob", hb["pk_blob"])), lb)
                 return out[:B]
-            elif self.graphs is True:
-                out = self._replay((B, T, max_len), host, to_dev, max_len)   # (the longest text sizes the attention's LDS window: part of the shape)
+            elif self.graphs and self.large_graphs and max_len <= self.FUSED_MAX_TOKENS and T >= self.LARGE_TOKEN_GRANULE:
+                # a large batch of questions (BASELINE config 5: 1024 texts, ~20 K tokens): its ~230 launches cost a busy host 15 - 35 ms
+                # per encode (measured) against 15 ms of GPU time. Canonical shape = real tokens padded to a multiple of
+                # LARGE_TOKEN_GRANULE with one-token dummy texts (<= 5 % more rows at 20 K tokens; nobody reads their outputs), the
+                # longest text rounded to 16 / 32 / 64: consecutive batches of a serving loop hit the same graph, ONE launch per encode.
+                g = self.LARGE_TOKEN_GRANULE
+                Tp = -(-T // g) * g
+                extra = Tp - T
+                lb = 16 if max_len <= 16 else (32 if max_len <= 32 else 64)
+                padded = {"pk_tok": torch.from_numpy(np.concatenate([host["pk_tok"].numpy(), np.full(extra, self.pad, dtype=np.int64)])),
+                          "pk_pos": torch.from_numpy(np.concatenate([host["pk_pos"].numpy(), np.full(extra, self.pad + 1, dtype=np.int64)])),
+                          "pk_first": host["pk_first"],
+                          "pk_tfirst": torch.from_numpy(np.concatenate([host["pk_tfirst"].numpy(), np.arange(T, Tp, dtype=np.int32)])),
+                          "pk_tlen": torch.from_numpy(np.concatenate([host["pk_tlen"].numpy(), np.ones(extra, dtype=np.int32)]))}
+                big = [k_ for k_ in self._graph if k_[0] == "large"]
+                key = ("large", B, Tp, lb)
+                if key not in self._graph and len(big) >= self.MAX_LARGE_GRAPHS:
+                    self._graph.pop(big[0])                       # each holds the activations of ~Tp tokens: keep few
+                out = self._replay(key, padded, to_dev, lb)
                 if out is not None:
                     return out
-            return self._fused_forward(*(to_dev(n, host[n]) for n in self._ORDER), max_len)
+                return self._fused_forward(*(to_dev(n, padded[n]) for n in self._ORDER), lb)
+            elif self.graphs is True:
+                nqb = int(host["pk_qb"].shape[0]) if "pk_qb" in host else 0
+                out = self._replay((B, T, max_len, nqb), host, to_dev, max_len)   # (the longest text sizes the attention's LDS window: part of the shape)
+                if out is not None:
+                    return out
+            return self._fused_forward(*(to_dev(n, host[n]) for n in self._ORDER), max_len, to_dev("pk_qb", host["pk_qb"]) if "pk_qb" in host else None)
         tok, pos, first_d = (to_dev(n, host[n]) for n in ("pk_tok", "pk_pos", "pk_first"))
         x = self.ln(self.word(tok) + self.pos(pos) + self.typ.weight[0])                                         # [T][H]
         flat_d = to_dev("pk_flat", torch.from_numpy(row * S + col))                                              # slot of packed token t in the padded [B*S] layout
@@ -414,7 +469,7 @@ class EmbeddingProvider:
                            max_position_embeddings=514)
             torch.manual_seed(0)
             model = XLMRobertaModel(XLMRobertaConfig(**cfg), add_pooling_layer=False)
-            self._tokenizer = _HashTokenizer(cfg["vocab_size"], max_len=min(512, cfg["max_position_embeddings"] - 2))
+            self._tokenizer = _HashTokenizer(cfg["vocab_size"], max_len=min(MAX_SEQ_LENGTH, cfg["max_position_embeddings"] - 2))   # (the reference caps texts at 8192 tokens, embedding_provider.py:30)
         else:
             local = _resolve_local_dir(self.model_name, self.cache_dir)
             if local is None:
@@ -541,6 +596,16 @@ class EmbeddingProvider:
     @torch.no_grad()
     def _encode_raw(self, texts: List[str]) -> torch.Tensor:
         """un-normalised CLS embeddings, fp32, on the model's device, in input order"""
+        if self._packed is not None and len(texts) <= self._packed.SMALL_TEXTS and str(self.device).startswith("cuda"):
+            # the online path — one question, or a question's sub-queries: nothing to sort (the packed forward pads nothing), no row
+            # permutation to undo: tokenise, ONE pinned copy, the replayed forward, one device copy of the rows handed back
+            enc = self._tokenizer(list(texts))
+            lens_np = enc["attention_mask"].numpy().sum(axis=1)   # (numpy, not torch: see _encode_raw's note on host-side tensor ops)
+            cls = self._packed.cls(enc["input_ids"], lens_np, self._h2d)
+            self.last_encode_stats = {"texts": len(texts), "tokens_real": int(lens_np.sum()), "tokens_padded": int(lens_np.sum()),
+                                      "tokens_padded_one_width": int(enc["input_ids"].numel()), "buckets": [{"rows": len(texts), "width": int(lens_np.max())}],
+                                      "real_over_padded": 1.0}
+            return cls.clone()                                    # (the forward's output buffer belongs to its graph: the next replay overwrites it)
         order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))   # length-sorted batches, like sentence-transformers
         out = torch.empty((len(texts), self._dims), dtype=torch.float32, device=self.device)
         stats = {"texts": len(texts), "tokens_real": 0, "tokens_padded": 0, "tokens_padded_one_width": 0, "buckets": []}
@@ -550,10 +615,15 @@ class EmbeddingProvider:
             idx = order[a: a + self.batch_size]
             enc = self._tokenizer([texts[i] for i in idx])
             ids, att = enc["input_ids"], enc["attention_mask"]
-            lens = att.sum(dim=1)
-            by_len = torch.argsort(lens, descending=True, stable=True)      # characters were a proxy: now by token count
-            ids, att, lens_np = ids[by_len], att[by_len], lens[by_len].numpy()
-            rows = [idx[i] for i in by_len.tolist()]
+            # Host-side bookkeeping in NUMPY. torch's CPU operations run on its intra-op thread pool, and on a box whose cgroup grants
+            # fewer cores than the pool has threads a reduction over a [64][1000] mask takes 50 ms instead of 30 us (measured: this
+            # container, 8 threads; `attention_mask.sum(dim=1)` alone). That — not launches — was the "busy host" of DESIGN.md §10's
+            # c5 numbers (an encode issued in 15 - 35 ms) and 2/3 of an ingest batch's wall time.
+            lens_all = att.numpy().sum(axis=1)
+            by_np = np.argsort(-lens_all, kind="stable")                     # characters were a proxy: now by token count
+            by_len = torch.from_numpy(by_np)
+            ids, att, lens_np = torch.from_numpy(ids.numpy()[by_np]), torch.from_numpy(att.numpy()[by_np]), lens_all[by_np]
+            rows = [idx[i] for i in by_np.tolist()]
             cuts = [0, int(lens_np.shape[0])] if self._packed is not None else self._bucket_cuts(lens_np)   # (packed: padding costs the attention only)
             stats["tokens_real"] += int(lens_np.sum())
             stats["tokens_padded_one_width"] += int(ids.shape[0] * ids.shape[1])

@@ -93,6 +93,51 @@ def torch_queries(b: int, dim: int, device, total_rows: int = 0, return_planted:
     return (q, planted) if return_planted else q
 
 
+# ---- an embedding-like corpus ---------------------------------------------------------------------------------
+# Real sentence embeddings are not i.i.d. noise: they share a mean direction (anisotropy: two unrelated BGE-M3 vectors have a
+# cosine around 0.4 - 0.6), and the reference stores a document's chunks back to back (`heading\n\ntext` of consecutive chunks,
+# reference src/processing/create_chromadb_index.py:300-387), i.e. runs of near-duplicates. Here: row = mu + d_doc + sigma_doc * eps
+# with |mu| = |d_doc| = 1, eps ~ N(0, I / dim) (so unrelated rows have cosine ~ 0.5), EMBED_DOCS documents of total_rows / EMBED_DOCS
+# CONTIGUOUS chunks each, sigma_doc uniform in [0.2, 0.6] (chunks of one document: cosine 0.85 - 0.98); a query is a document's
+# vector seen through noise 0.3. Deterministic per chunk of 65 536 rows like the N(0,1) corpus.
+EMBED_DOCS = 2000
+
+
+def _embed_tables(dim: int, device):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(777)
+    mu = torch.randn((dim,), generator=g, device=device, dtype=torch.float32)
+    mu = mu / mu.norm()
+    docs = torch.randn((EMBED_DOCS, dim), generator=g, device=device, dtype=torch.float32)
+    docs = docs / docs.norm(dim=1, keepdim=True)
+    sigma = 0.2 + 0.4 * torch.rand((EMBED_DOCS,), generator=g, device=device, dtype=torch.float32)
+    return mu, docs, sigma
+
+
+def torch_embedlike_chunk(j: int, rows: int, dim: int, device, total_rows: int):
+    import torch
+    mu, docs, sigma = _embed_tables(dim, device)
+    doc_len = max(1, -(-total_rows // EMBED_DOCS))
+    r0 = j * CHUNK
+    doc = torch.clamp((torch.arange(r0, r0 + rows, device=device) // doc_len), max=EMBED_DOCS - 1)
+    g = torch.Generator(device=device)
+    g.manual_seed(5678 * 1000003 + j)
+    eps = torch.randn((rows, dim), generator=g, device=device, dtype=torch.float32) * (dim ** -0.5)
+    return mu[None, :] + docs[doc] + sigma[doc][:, None] * eps
+
+
+def torch_embedlike_queries(b: int, dim: int, device):
+    """b queries, each near one document: mu + d_doc + 0.3 * eps; -> (queries, document of each)"""
+    import torch
+    mu, docs, _ = _embed_tables(dim, device)
+    g = torch.Generator(device=device)
+    g.manual_seed(4321)
+    which = torch.randint(0, EMBED_DOCS, (b,), generator=g, device=device)
+    eps = torch.randn((b, dim), generator=g, device=device, dtype=torch.float32) * (dim ** -0.5)
+    return mu[None, :] + docs[which] + 0.3 * eps, which
+
+
 _WORDS = ("durée conservation données personnelles traitement registre sous-traitant responsable AIPD analyse impact consentement "
           "cookies traceurs vidéosurveillance salariés transfert hors union européenne violation notification CNIL délégué "
           "protection base légale intérêt légitime droit accès effacement portabilité sanction mise en demeure sécurité").split()

@@ -52,14 +52,13 @@ int main(void) {
     EXPECT(RDX_ERR_INVALID, rdx_enc_embed_f16(0, rows, rows, h16, h16, h16, 4, 768, h16, NULL));
     EXPECT(RDX_ERR_INVALID, rdx_enc_linear_small_f16(0, h16, h16, h16, 300, 16, 512, 0, h16, NULL));
     EXPECT(RDX_ERR_INVALID, rdx_enc_linear_small_f16(0, h16, h16, h16, 4, 24, 512, 0, h16, NULL));
-    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 33, 16, 512, 0, 16, NULL, 0, h16, NULL));
-    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 4, 16, 768, 0, 16, NULL, 0, h16, NULL));
-    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 4, 16, 512, 2, 16, NULL, 0, h16, NULL));
-    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 4, 16, 512, 0, 5, NULL, 0, h16, NULL));
-    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, rows, h16, h16, 1e-5f, NULL, h16, h16, NULL, 4, 16, 512, 0, 16, NULL, 0, h16, NULL));
-    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 4, 16, 512, 0, 16, NULL, 4096, h16, NULL));
+    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 33, 16, 512, 0, 16, h16, NULL));
+    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 4, 16, 768, 0, 16, h16, NULL));
+    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 4, 16, 512, 2, 16, h16, NULL));
+    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, NULL, NULL, NULL, 0.f, NULL, h16, h16, NULL, 4, 16, 512, 0, 5, h16, NULL));
+    EXPECT(RDX_ERR_INVALID, rdx_enc_stage_f16(0, h16, rows, h16, h16, 1e-5f, NULL, h16, h16, NULL, 4, 16, 512, 0, 16, h16, NULL));
     EXPECT(RDX_ERR_INVALID, rdx_merge_topk(0, out, rows, tf, 0, 1, 1, out, rows, tf, RDX_HOST, NULL));
-    EXPECT(RDX_ERR_INVALID, rdx_merge_topk(0, out, rows, tf, 1, 1, 0, out, rows, tf, RDX_HOST, NULL));
+    EXPECT(RDX_ERR_INVALID, rdx_merge_topk(0, out, rows, tf, 1, 1, -1, out, rows, tf, RDX_HOST, NULL));
     EXPECT(RDX_ERR_INVALID, rdx_merge_topk_packed(0, h16, 8, 1, 1, 1, out, rows, tf, NULL, NULL));
     EXPECT(RDX_ERR_INVALID, rdx_merge_topk_packed(0, h16, 32, 64, 1, 100, out, rows, tf, NULL, NULL));
     EXPECT(RDX_ERR_INVALID, rdx_signal_create(0, NULL));
@@ -68,8 +67,8 @@ int main(void) {
         EXPECT(RDX_ERR_INVALID, rdx_index_add(h, one, -1, RDX_HOST));
         EXPECT(RDX_ERR_INVALID, rdx_index_add(h, one, 1, 9));
         EXPECT(RDX_ERR_INVALID, rdx_index_set_option(h, "no_such_option", 1));
-        EXPECT(RDX_ERR_INVALID, rdx_search(h, one, 1, 0, NULL, out, rows, tf, RDX_HOST, NULL));
-        EXPECT(RDX_ERR_INVALID, rdx_index_get(h, rows, 1, out, RDX_HOST));
+        EXPECT(RDX_ERR_INVALID, rdx_search(h, one, 1, -1, NULL, out, rows, tf, RDX_HOST, NULL));
+        EXPECT(RDX_ERR_INVALID, rdx_index_get(h, NULL, 1, out, RDX_HOST));
         if (rdx_index_destroy(h) != RDX_OK) return 4;
     } else if (rc != RDX_ERR_HIP && rc != RDX_ERR_INVALID) {
         fprintf(stderr, "rdx_index_create without a GPU -> %d: %s\n", rc, rdx_last_error());

@@ -363,13 +363,13 @@ def test_fused_encoder_kernels_equal_the_torch_operations():
         ref = plain.embed_device(texts)
         assert got.shape == ref.shape
         assert float((torch.nn.functional.normalize(got, dim=1) - torch.nn.functional.normalize(ref, dim=1)).abs().max()) <= 2e-3, texts
-    assert len(fast._packed._graph) == 2                    # two canonical shapes: <= 16 tokens (one token block per stage) and <= 32
+    assert len(fast._packed._graph) == 3                    # three canonical shapes: 8, 16 and 24 tokens (multiples of 8 up to 32)
     a1, a2 = fast.embed_device(small[2]).clone(), fast.embed_device(small[2]).clone()
     assert torch.equal(a1, a2)
     many = [" ".join(f"w{i}" for i in range(j, j + 30)) for j in range(4)]      # 4 x 32 tokens: another canonical shape
     for _ in range(3):
         got = fast.embed_device(many).clone()
-    assert len(fast._packed._graph) == 3
+    assert len(fast._packed._graph) == 4
     assert float((torch.nn.functional.normalize(got, dim=1) - torch.nn.functional.normalize(plain.embed_device(many), dim=1)).abs().max()) <= 2e-3
     fast._packed.MAX_GRAPHS = 1                             # capturing a new shape pushes the least recently used ones out
     for _ in range(2):
@@ -384,14 +384,13 @@ def test_encoder_stage_kernel_vs_fp32_reference():
     """rdx_enc_stage_f16 (one projection of the single-question forward: LayerNorm prologue or plain / gathered input, the weight matrix
     streamed once by workgroups of 16 / 8 / 4 features, bias / erf GELU / residual epilogue) against a plain torch fp32 reference of the
     same op on the same fp16 inputs. Token counts 1..32 on both sides of the 16-token block, every K the kernel takes, with and without
-    the next stage's weight prefetch. Tolerance: fp16 output of fp32 accumulation (2e-3 relative to the row scale, as for
+    several input widths. Tolerance: fp16 output of fp32 accumulation (2e-3 relative to the row scale, as for
     rdx_enc_linear_small_f16); the stored LayerNorm output within one fp16 ulp of torch's fp32 LayerNorm."""
     import torch
     from rag_dpo_amd import _lib
     L = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator().manual_seed(21)
-    nxt = torch.zeros(3 * 1024 * 1024, dtype=torch.float16, device="cuda")          # "the next stage's weights" (6 MB, only touched)
     # LayerNorm prologue: qkv / FFN-up shapes
     for T, N, K, epi in ((1, 3072, 1024, 0), (16, 4096, 1024, 1), (17, 3072, 1024, 0), (20, 4096, 1024, 1), (32, 3072, 1024, 0), (32, 1024, 512, 1), (9, 1536, 512, 0)):
         s = (torch.randn((T, K), generator=g) * 1.7 + 0.3).half().cuda()
@@ -403,11 +402,11 @@ def test_encoder_stage_kernel_vs_fp32_reference():
             ln.bias.copy_(torch.randn(K, generator=g) * 0.2)
         ln = ln.half().cuda()
         y_ref = torch.nn.functional.layer_norm(s.float(), (K,), ln.weight.float(), ln.bias.float(), 1e-5)
-        for pf in (0, nxt.numel() * 2):
+        for rep in range(2):
             out = torch.full((T, N), float("nan"), dtype=torch.float16, device="cuda")
             y = torch.full((T, K), float("nan"), dtype=torch.float16, device="cuda")
             rc = L.rdx_enc_stage_f16(0, s.data_ptr(), None, ln.weight.data_ptr(), ln.bias.data_ptr(), 1e-5, y.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                     None, T, N, K, epi, 0, nxt.data_ptr() if pf else None, pf, out.data_ptr(), st)
+                                     None, T, N, K, epi, 0, out.data_ptr(), st)
             assert rc == 0, _lib.last_error()
             torch.cuda.synchronize()
             assert torch.isfinite(out).all() and torch.isfinite(y).all()
@@ -431,7 +430,7 @@ def test_encoder_stage_kernel_vs_fp32_reference():
                 for gather in (False, True):
                     out = torch.full((T, N), float("nan"), dtype=torch.float16, device="cuda")
                     rc = L.rdx_enc_stage_f16(0, x.data_ptr(), idx.data_ptr() if gather else None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(),
-                                             res.data_ptr(), T, N, K, epi, fpb, nxt.data_ptr(), 1 << 20, out.data_ptr(), st)
+                                             res.data_ptr(), T, N, K, epi, fpb, out.data_ptr(), st)
                     assert rc == 0, _lib.last_error()
                     xs, rs = (x[idx], res[idx]) if gather else (x[:T], res[:T])
                     want = xs.float() @ w.float().T + b.float()
@@ -444,11 +443,11 @@ def test_encoder_stage_kernel_vs_fp32_reference():
                     err = float((out.float() - want).abs().max())
                     assert err <= 3e-3 * max(1.0, float(want.abs().max())), (T, N, K, fpb, epi, gather, err)
     # argument checks
-    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 33, N, K, 0, 16, None, 0, out.data_ptr(), 0) != 0
-    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, 768, 0, 16, None, 0, out.data_ptr(), 0) != 0
-    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, K, 2, 16, None, 0, out.data_ptr(), 0) != 0
-    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, K, 0, 5, None, 0, out.data_ptr(), 0) != 0
-    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 0, N, K, 0, 16, None, 0, out.data_ptr(), 0) == 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 33, N, K, 0, 16, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, 768, 0, 16, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, K, 2, 16, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 4, N, K, 0, 5, out.data_ptr(), 0) != 0
+    assert L.rdx_enc_stage_f16(0, x.data_ptr(), None, None, None, 0.0, None, w.data_ptr(), b.data_ptr(), None, 0, N, K, 0, 16, out.data_ptr(), 0) == 0
 
 
 @pytest.mark.gpu
@@ -476,6 +475,61 @@ def test_encoder_attention_small_kernel_vs_fp32_reference():
         assert float((got - want).abs().max()) <= 3e-3, (heads, lens, float((got - want).abs().max()))
     assert L.rdx_enc_attention_small_f16(0, qd.data_ptr(), tf.data_ptr(), 33, heads, 64, 0.125, ctx.data_ptr(), 0) != 0
     assert L.rdx_enc_attention_small_f16(0, qd.data_ptr(), tf.data_ptr(), T, heads, 32, 0.125, ctx.data_ptr(), 0) != 0
+
+
+@pytest.mark.gpu
+def test_encoder_attention_mfma_kernel_vs_fp32_reference():
+    """rdx_enc_attention_mfma_f16 (flash-style attention of packed texts of any length: the corpus side, chunk texts of hundreds of
+    tokens) against the plain fp32 torch reference of the same op: ragged lengths 1 .. 1500 on both sides of the 32-key tile and the
+    64-query block, many short texts, one text only. Tolerance 3e-3: fp16 output, probabilities rounded to fp16 before PV."""
+    import torch
+    from rag_dpo_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(9)
+    for heads, lens in ((16, [1, 64, 7, 200, 33, 2, 65, 31, 32, 128, 129]), (2, [1500, 1, 1023, 1024, 1025]), (4, list(rng.integers(1, 90, size=150))), (16, [300])):
+        H, T = heads * 64, int(sum(lens))
+        g = torch.Generator().manual_seed(T)
+        qkv = (torch.randn((T, 3 * H), generator=g) * 1.5).half()
+        lens_a = np.asarray(lens, dtype=np.int64)
+        first = np.cumsum(lens_a) - lens_a
+        nb = (lens_a + 63) // 64
+        tix = np.repeat(np.arange(len(lens)), nb)
+        q0 = (np.arange(int(nb.sum())) - np.repeat(np.cumsum(nb) - nb, nb)) * 64
+        qb = torch.from_numpy(np.stack([first[tix], lens_a[tix], q0, np.zeros_like(q0)], axis=1).astype(np.int32)).cuda()
+        qd = qkv.cuda()
+        ctx = torch.full((T, H), float("nan"), dtype=torch.float16, device="cuda")
+        rc = L.rdx_enc_attention_mfma_f16(0, qd.data_ptr(), qb.data_ptr(), int(qb.shape[0]), heads, 64, 0.125, ctx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _lib.last_error()
+        want = _attention_reference(qkv, [int(n) for n in lens], heads)
+        torch.cuda.synchronize()
+        got = ctx.float().cpu()
+        assert torch.isfinite(got).all()
+        assert float((got - want).abs().max()) <= 3e-3, (heads, lens[:5], float((got - want).abs().max()))
+    assert L.rdx_enc_attention_mfma_f16(0, qd.data_ptr(), qb.data_ptr(), 1, heads, 32, 0.125, ctx.data_ptr(), 0) != 0
+    assert L.rdx_enc_attention_mfma_f16(0, qd.data_ptr(), qb.data_ptr(), 0, heads, 64, 0.125, ctx.data_ptr(), 0) == 0
+
+
+@pytest.mark.gpu
+def test_long_texts_take_the_packed_forward_with_the_mfma_attention():
+    """chunk-like texts (up to several hundred tokens: what the indexer embeds, reference create_chromadb_index.py:300-387) stay on the
+    packed forward — MFMA attention, add + LayerNorm kernels, no padding — and agree with the torch-operations forward and the module"""
+    import torch
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    rng = np.random.default_rng(11)
+    words = [f"w{i}" for i in range(300)]
+    texts = [" ".join(rng.choice(words, size=int(n))) for n in (400, 3, 70, 129, 64, 65, 250, 1, 33)]
+
+    def make(fused, packed=True):
+        p = EmbeddingProvider(model_name="random-init:mid", device="cuda:0", dtype=torch.float16, batch_size=512)
+        p.fused_kernels, p.packed_forward = fused, packed
+        return p.load()
+    fast, plain, module = make(None), make(False), make(False, packed=False)
+    assert fast._packed.long_attention
+    got = fast.embed_device(texts)
+    for ref in (plain.embed_device(texts), module.embed_device(texts)):
+        cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=1)
+        assert float((1 - cos).abs().max()) <= 1e-5, float((1 - cos).abs().max())
+    assert fast.last_encode_stats["tokens_real"] == sum(len(t.split()) + 2 for t in texts)
 
 
 @pytest.mark.gpu

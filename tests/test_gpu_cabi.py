@@ -26,3 +26,25 @@ def test_c_abi_argument_checks_with_a_device(tmp_path):
     spec.loader.exec_module(m)
     out = m.build_and_run_errors(tmp_path)
     assert "(with a device)" in out
+
+
+def test_sharded_overflow_rehearsal_repeats_the_exchange_on_every_rank():
+    """the repeated-exchange branch of the sharded search with three ranks: `bench.py --gpus 3 --set cand_cap=8` makes
+    EVERY search overflow its candidate segments, so every rank re-runs queries after its kernels and all ranks must learn it from
+    the merged flags word and exchange a second time. Three processes share this box's one GPU and the collective runs over gloo
+    through host memory (RDX_BENCH_REHEARSAL=1: the rehearsal form; the packed layout, the flags word, the merge kernel and the
+    rdx_signal wait are the real ones). Asserts: two exchanges per search, the same merged checksum on all ranks, and the merged
+    lists equal to the per-shard exact scans merged the same way."""
+    import json
+    import sys
+    env = dict(os.environ, RDX_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--workload", "c3", "--rows", "300000", "--steps", "3",
+                          "--warmup", "1", "--no-cpu", "--set", "cand_cap=8"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 3 and d["rccl"]["world"] == 3
+    chk, bd = d["distributed_check"], d["step_breakdown"]
+    assert chk["merged_identical_on_all_ranks"] is True and chk["per_shard_exact_scan_merged_equals_mfma_merged"] is True, chk
+    assert bd["exchanges"] == 2 * bd["steps"], bd                   # every search: the first exchange, then the repeated one
+    assert d["path_stats"]["retried_queries"] > 0 or d["path_stats"]["exact_fallback_queries"] > 0

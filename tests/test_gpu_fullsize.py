@@ -104,3 +104,65 @@ def test_full_size_properties(rows, b, k, oracle):
     np.testing.assert_array_equal(gs, es)
     ix.close()
     torch.cuda.empty_cache()
+
+
+def test_config5_as_a_chain_full_size(oracle):
+    """BASELINE config 5 end to end on one GPU: 1024 query TEXTS -> `embed_device` (XLM-R-large architecture, random-init fp16: the
+    packed forward with librdx's kernels) -> straight into the search of a 10 M-row bf16 corpus held at 4 B/element (`compact_master`:
+    raw bf16 rows + one divisor per row), nothing leaving the device in between. Encoder VALUES are unpinned (no BGE-M3 weights
+    offline); what is checked is the chain: whatever vectors the encoder hands over, the search must return their exact neighbours.
+    Same properties as above — order, the oracle's score of every returned stored row, the exact full scan K5 over ALL rows for 32
+    queries, the exact oracle top-k of a 128 K-row sample — plus: handing the same vectors over as host floats gives the same bits."""
+    import torch
+    from rag_dpo_amd import engine as eng
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    rows, b, k, dim = 10_000_000, 1024, 10, 1024
+    ix = eng.HipIndex(dim)
+    ix.set_option("compact_master", 1)
+    ix.reserve(rows)
+    for j, r0 in enumerate(range(0, rows, synth.CHUNK)):
+        ix.add_bf16(synth.torch_corpus_chunk(j, min(synth.CHUNK, rows - r0), dim, "cuda:0").to(torch.bfloat16))
+    torch.cuda.synchronize()
+    assert len(ix) == rows
+    p = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device="cuda:0", dtype=torch.float16, batch_size=1024).load()
+    texts = synth.query_texts(b)
+    qd = p.embed_device(texts)                                       # [1024][1024] fp32 on the device, not normalised (the search runs K1)
+    assert qd.is_cuda and qd.shape == (b, dim) and bool(torch.isfinite(qd).all())
+    s_d = torch.empty((b, k), dtype=torch.float32, device="cuda")
+    r_d = torch.empty((b, k), dtype=torch.int64, device="cuda")
+    c_d = torch.empty((b,), dtype=torch.int32, device="cuda")
+    ix.search_device(qd, k, s_d, r_d, c_d)
+    torch.cuda.synchronize()
+    st = ix.last_stats()
+    assert st["path"] == 0, st
+    s, r, c, q = s_d.cpu().numpy(), r_d.cpu().numpy(), c_d.cpu().numpy(), qd.cpu().numpy()
+    assert (c == k).all()
+    sd = s.astype(np.float64)
+    assert (np.diff(sd, axis=1) <= 0).all()
+    assert (np.diff(r, axis=1)[np.diff(sd, axis=1) == 0] > 0).all()
+    assert all(len(set(row.tolist())) == k for row in r)
+    rng = np.random.default_rng(5)
+    qhat = oracle.normalize_rows(q)
+    for i in rng.choice(b, size=64, replace=False).tolist():         # the oracle's score of every returned STORED row (bf16 values, fp64 divisor)
+        np.testing.assert_array_equal(oracle.scores(ix.get(r[i]), qhat[i]), s[i])
+    pick = np.sort(rng.choice(b, size=32, replace=False))
+    ix.set_option("force_exact", 1)                                  # K5: fp32 arithmetic on the recomputed normalised rows, no MFMA, all rows
+    xs, xr, xc = ix.search(q[pick], k)
+    assert ix.last_stats()["path"] == 1
+    ix.set_option("force_exact", 0)
+    np.testing.assert_array_equal(xr, r[pick])
+    np.testing.assert_array_equal(xs, s[pick])
+    rows_s = np.sort(rng.choice(rows, size=131072, replace=False))
+    allow = np.zeros(rows, dtype=bool)
+    allow[rows_s] = True
+    gs, gr, gc = ix.search(q[:16], k, oracle.pack_mask(allow, rows))
+    es, er, ec = oracle.cosine_topk(ix.get(rows_s), q[:16], k)
+    np.testing.assert_array_equal(gr, rows_s[er])
+    np.testing.assert_array_equal(gs, es)
+    # the reference's hand-over (the vectors as host floats, src/utils/embedding_provider.py:147) answers exactly like the device hand-over
+    hs, hr, hc = ix.search(q[:8], k)
+    np.testing.assert_array_equal(hr, r[:8])
+    np.testing.assert_array_equal(hs, s[:8])
+    p.unload()
+    ix.close()
+    torch.cuda.empty_cache()

@@ -27,9 +27,17 @@ def test_random_shapes_match_oracle(oracle):
             corpus[rng.integers(0, n, n // 50)] = corpus[rng.integers(0, n, n // 50)]
             a = int(rng.integers(0, n - 50))
             corpus[a:a + 50] = corpus[a] + 0.01 * rng.standard_normal((50, dim)).astype(np.float32)
+        big_cluster = n >= 5000 and rng.random() < 0.35
+        if big_cluster:                       # a "document": thousands of rows closer together than the coarse pass can tell apart
+            m = int(rng.choice([1100, 2500, 4000]))   # (the 2E band then holds more rows than the ranking arrays: re-scored in place)
+            a = int(rng.integers(0, n - m))
+            corpus[a:a + m] = corpus[a] + float(rng.choice([0.003, 0.02])) * rng.standard_normal((m, dim)).astype(np.float32)
+            corpus[a + 7] = corpus[a + 3]     # exact ties inside the band
         q = rng.standard_normal((b, dim)).astype(np.float32)
         if n > 10:
             q[: max(1, b // 8)] = corpus[rng.integers(0, n, max(1, b // 8))] + 0.1 * rng.standard_normal((max(1, b // 8), dim)).astype(np.float32)
+        if big_cluster:
+            q[-max(1, b // 4):] = corpus[a] + 0.1 * rng.standard_normal((max(1, b // 4), dim)).astype(np.float32)   # questions about that document
         allow = None
         r = rng.random()
         if r < 0.3:
@@ -61,6 +69,8 @@ def test_random_shapes_match_oracle(oracle):
             opts["small_scan"] = 0      # (default 1: split-K main scan for <= 64 queries on small corpora)
         if rng.random() < 0.3:
             opts["half_boot"] = 0       # (default 1: 129..256 queries sample their threshold as two 128-query tiles per corpus tile)
+        if rng.random() < 0.3:
+            opts["spread_boot"] = 0     # (default 1: the threshold sample of > 64 queries is every div-th 32-row block, not every div-th tile)
         for name, v in opts.items():
             ix.set_option(name, v)
         es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, k, allow)

@@ -576,7 +576,7 @@ def test_speculative_threshold_is_verified(eng, oracle):
     fool = corpus.copy()
     for j in range(8):                                     # 8 near-copies of each of the first 3 queries in tile 0, one per wave's 32-row
         fool[32 * j: 32 * j + 3] = q[:3] + 0.05 * rng.standard_normal((3, d)).astype(np.float32)   # block (8 distinct bootstrap sets); nothing else is close
-    ix = _index(eng, fool)
+    ix = _index(eng, fool, spread_boot=0)                  # (the whole-tile sample this corpus is built against: tile 0 = blocks 0..7)
     st = _check(oracle, ix, fool, q, k, expect_path=0)
     assert st["tau_rank"] < k and st["retried_queries"] >= 3, st
     st = _check(oracle, ix, fool, q, k, expect_path=0)     # backoff: proven thresholds now, nobody retried
@@ -740,14 +740,53 @@ def test_clustered_rows_get_a_second_mfma_pass(eng, oracle):
     corpus[a:a + m] = v + sigma * rng.standard_normal((m, dim)).astype(np.float32)
     q = rng.standard_normal((40, dim)).astype(np.float32)
     q[:5] = v + 0.1 * rng.standard_normal((5, dim)).astype(np.float32)
-    ix = _index(eng, corpus, force_fast=1, cand_cap=64, split_boot=0)     # (whole-tile sample: the stride this corpus is built against)
+    ix = _index(eng, corpus, force_fast=1, cand_cap=64, split_boot=0, spread_boot=0)   # (whole-tile sample: the stride this corpus is built against)
     st = _check(oracle, ix, corpus, q, k, expect_path=0)
     assert st["retried_queries"] == 5 and st["exact_queries"] == 0, st
     ix.set_option("split_boot", 1)                 # the split-K bootstrap samples 32-row blocks spread over the corpus: four of them
     st = _check(oracle, ix, corpus, q, k, expect_path=0)   # fall into the cluster, the threshold sees it, nothing overflows
     assert st["retried_queries"] == 0 and st["exact_queries"] == 0, st
     ix.set_option("split_boot", 0)
+    ix.set_option("spread_boot", 1)                # the tile kernel's sample as every 36th 32-ROW block (round 4): the cluster's 160 blocks hold
+    st = _check(oracle, ix, corpus, q, k, expect_path=0)   # four or five of them — the same rows sampled, eight times finer
+    assert st["retried_queries"] == 0 and st["exact_queries"] == 0, st
+    ix.set_option("spread_boot", 0)
     ix.set_option("retry", 0)                      # without the second chance the same queries pay the exact scan
     st = _check(oracle, ix, corpus, q, k, expect_path=0)
     assert st["retried_queries"] == 0 and st["exact_queries"] == 5, st
+    ix.close()
+
+
+def test_near_duplicate_band_is_rescored_in_place(eng, oracle):
+    """a "document" of thousands of chunks closer together than the fp16 coarse pass can tell apart (their scores lie inside the 2E band
+    of the k-th): the band holds more rows than k_refine's ranking arrays. Until round 4 such a query paid the exact full scan of the
+    whole corpus; now the band's members are re-scored exactly in place and the k best selected (refine_kernel.hpp). Small and large
+    batches (both bootstrap forms), exact ties inside the band, a `where` bitmap through the band; the oracle's ids and score bits,
+    and no query handed to the exact scan. More than 1024 rows IDENTICAL to the k-th still need the exact scan — and get it."""
+    rng = np.random.default_rng(23)
+    n, dim, k = 120_000, 256, 10
+    corpus = rng.standard_normal((n, dim)).astype(np.float32)
+    a, m = 40_000, 3000
+    corpus[a:a + m] = corpus[a] + 0.004 * rng.standard_normal((m, dim)).astype(np.float32)
+    corpus[a + 11] = corpus[a + 5]
+    corpus[a + 2000] = corpus[a + 5]
+    for b in (8, 200):
+        q = rng.standard_normal((b, dim)).astype(np.float32)
+        q[: b // 2] = corpus[a] + 0.05 * rng.standard_normal((b // 2, dim)).astype(np.float32)
+        ix = _index(eng, corpus, force_fast=1)
+        st = _check(oracle, ix, corpus, q, k, expect_path=0)
+        assert st["exact_queries"] == 0, st
+        assert st["rescored"] >= (b // 2) * 1025, st                 # the band really was larger than the ranking arrays
+        allow = rng.random(n) < 0.5
+        st = _check(oracle, ix, corpus, q, k, allow, expect_path=0)
+        assert st["exact_queries"] == 0, st
+        st = _check(oracle, ix, corpus, q, 100, expect_path=0)
+        assert st["exact_queries"] == 0, st
+        ix.close()
+    corpus[a:a + 1200] = corpus[a]                                   # 1200 identical rows: ties that only the exact scan orders
+    q = rng.standard_normal((4, dim)).astype(np.float32)
+    q[0] = corpus[a]                                                 # the identical rows ARE the best: the k-th score is shared by 1200 rows
+    ix = _index(eng, corpus, force_fast=1)
+    st = _check(oracle, ix, corpus, q, k, expect_path=0)
+    assert st["exact_queries"] == 1, st
     ix.close()

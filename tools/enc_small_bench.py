@@ -1,5 +1,5 @@
 """Developer: latency of the single-question forward (embed_device([q]) + synchronise, HIP-graph replay) under the knobs of
-rag_dpo_amd/embedding_provider.py `_PackedEncoder` (RDX_ENC_FPB_O, RDX_ENC_FPB_F2, RDX_ENC_PREFETCH). One JSON line.
+rag_dpo_amd/embedding_provider.py `_PackedEncoder` (RDX_ENC_FPB_O, RDX_ENC_FPB_F2). One JSON line.
   python tools/enc_small_bench.py [reps]         RDX_ENC_OLD=1: round 3's seven-launches-per-layer path for comparison"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,11 +11,11 @@ if os.environ.get("RDX_ENC_OLD"):
     _PackedEncoder.STAGE_TOKENS = 0
 p = EmbeddingProvider(model_name="random-init:xlm-roberta-large", device="cuda:0", dtype=torch.float16, batch_size=64).load()
 texts = synth.query_texts(64)
-short = [t for t in texts if len(t.split()) + 2 <= 16][:4]
-longq = [t for t in texts if 17 <= len(t.split()) + 2 <= 32][:8]
-out = {"fpb_o": p._packed.stage_fpb_o, "fpb_f2": p._packed.stage_fpb_f2, "prefetch": p._packed.stage_prefetch,
+tk = lambda t: len(t.split()) + 2
+short, mid, longq = [t for t in texts if tk(t) <= 16][:4], [t for t in texts if 17 <= tk(t) <= 24][:6], [t for t in texts if 25 <= tk(t) <= 32][:6]
+out = {"fpb_o": p._packed.stage_fpb_o, "fpb_f2": p._packed.stage_fpb_f2,
        "old_path": bool(os.environ.get("RDX_ENC_OLD"))}
-for name, sample in (("q17_32_tokens", longq), ("q_le16_tokens", short)):
+for name, sample in (("q25_32_tokens", longq), ("q17_24_tokens", mid), ("q_le16_tokens", short)):
     if not sample:
         continue
     for t in sample:
