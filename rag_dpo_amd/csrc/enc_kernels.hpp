@@ -329,8 +329,10 @@ __global__ __launch_bounds__(256) void k_enc_attention_mfma(const _Float16* __re
     const int k_slot = (sk * 8 + (sc ^ ((sk >> 1) & 7))) * 8;                                   // halves
     const int v_slot = sk * 64 + ((((sc >> 1) ^ ((sk >> 1) & 3)) << 1) | (sc & 1)) * 8;
     const _Float16* kv0 = qkv + (int64_t)first * row + H + h * 64 + sc * 8;
-    half8 kr, vr;
-    auto load_tile = [&](int t) __attribute__((always_inline)) {
+    // two tiles travel in registers (sets a and b): the tile after next is requested while this one is multiplied — one tile's arithmetic
+    // (~300 cycles) does not cover a global load's ~2 000
+    half8 kra, vra, krb, vrb;
+    auto load_tile = [&](int t, half8& kr, half8& vr) __attribute__((always_inline)) {
         const int key = t * ATT_KT + sk;
         if (key < len) {
             const _Float16* p = kv0 + (int64_t)key * row;
@@ -342,9 +344,11 @@ __global__ __launch_bounds__(256) void k_enc_attention_mfma(const _Float16* __re
         }
     };
     const int ntiles = (len + ATT_KT - 1) / ATT_KT;
-    load_tile(0);
-    *reinterpret_cast<half8*>(&ks[0][k_slot]) = kr;
-    *reinterpret_cast<half8*>(&vs[0][v_slot]) = vr;
+    load_tile(0, kra, vra);
+    *reinterpret_cast<half8*>(&ks[0][k_slot]) = kra;
+    *reinterpret_cast<half8*>(&vs[0][v_slot]) = vra;
+    if (ntiles > 1) load_tile(1, kra, vra);
+    if (ntiles > 2) load_tile(2, krb, vrb);
     __syncthreads();
     float m = -INFINITY, lpart = 0.f;
     f32x4 o[4];
@@ -367,9 +371,7 @@ __global__ __launch_bounds__(256) void k_enc_attention_mfma(const _Float16* __re
         va[j] = r * 64 + tp * 4;              // + the swizzled 16-dim block, per dt, below
     }
     const int vsw0 = ((4 * g + tq) >> 1) & 3, vsw1 = ((16 + 4 * g + tq) >> 1) & 3;
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile(t + 1);
+    auto tile_step = [&](int t, int buf, half8& kr, half8& vr) __attribute__((always_inline)) {   // kr / vr: tile t + 1 (this step's register set)
         f32x4 st[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -413,8 +415,13 @@ __global__ __launch_bounds__(256) void k_enc_attention_mfma(const _Float16* __re
         if (t + 1 < ntiles) {
             *reinterpret_cast<half8*>(&ks[buf ^ 1][k_slot]) = kr;
             *reinterpret_cast<half8*>(&vs[buf ^ 1][v_slot]) = vr;
+            if (t + 3 < ntiles) load_tile(t + 3, kr, vr);     // the set is free again: the tile three ahead
         }
         __syncthreads();
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        tile_step(t, 0, kra, vra);
+        if (t + 1 < ntiles) tile_step(t + 1, 1, krb, vrb);
     }
     float l = lpart;
     l += __shfl_xor(l, 16);

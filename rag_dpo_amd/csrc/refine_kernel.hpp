@@ -231,36 +231,108 @@ __device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, con
     __syncthreads();
     const int p = n_p;
     if (threadIdx.x == 0) atomicAdd(&ctr->rescored, (unsigned long long)p);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* q4 = reinterpret_cast<const float4*>(qhat + (int64_t)q * dim);
+    const int n4 = dim >> 2, nw = (int)(blockDim.x >> 6);
+    // exact re-score of `cnt` candidates, one wave per candidate row: row_at(i) = its row, put(i, s) takes its exact score
+    auto rescore = [&](int cnt, auto row_at, auto put) __attribute__((always_inline)) {
+        if (n4 <= 256) {
+            // dim <= 1024: the query sits in registers as doubles (converted once per block, not once per candidate), a row's four
+            // 1 KiB pieces are requested together and the NEXT candidate's pieces before this one is summed. Same products, same
+            // order per lane, same butterfly as exact_score(): the same bits. (c3: k = 100, ~140 candidates per query = 9 dependent
+            // round trips to random HBM rows per wave before.)
+            int gi[4];
+            bool gv[4];
+            float4 qf[4];                                   // (kept as floats, widened at use: 16 registers instead of 32)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gv[u] = lane + 64 * u < n4;
+                gi[u] = gv[u] ? lane + 64 * u : n4 - 1;
+                const float4 qq = q4[gi[u]];
+                qf[u] = gv[u] ? qq : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            auto load_row = [&](int i, float4 (&c)[4]) __attribute__((always_inline)) {
+                const MasterRow row4 = master_row(master, row_at(i), dim);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c[u] = row4[gi[u]];
+            };
+            float4 cur[4], nxt[4];
+            if (wave < cnt) load_row(wave, cur);
+            for (int i = wave; i < cnt; i += nw) {
+                load_row(i + nw < cnt ? i + nw : i, nxt);   // (the last one re-reads its own row: no branch around loads)
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc += (double)qf[u].x * (double)cur[u].x;
+                    acc += (double)qf[u].y * (double)cur[u].y;
+                    acc += (double)qf[u].z * (double)cur[u].z;
+                    acc += (double)qf[u].w * (double)cur[u].w;
+                }
+                const float sx = (float)wave_sum(acc);
+                if (lane == 0) put(i, sx);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            }
+            // (a third row in flight per wave — the loop is 9 dependent ~2 us round trips at c3 — needs 16 more registers than the
+            //  1024-thread block has: 17 spilled. Measured instead: profiles/r04/refine_stamps.txt)
+        } else {
+            for (int i = wave; i < cnt; i += nw) {
+                const float sx = exact_score(master_row(master, row_at(i), dim), q4, n4, lane);
+                if (lane == 0) put(i, sx);
+            }
+        }
+    };
     if (p > REFINE_PMAX) {
         // More rows inside the 2E band than the ranking arrays hold: near-duplicate rows stored together (a document's chunks: their
         // scores lie closer together than the coarse pass can tell apart, so the band holds hundreds to thousands of them). Until
         // round 4 such a query paid the exact full scan of the WHOLE corpus (7 ms per 4 queries at 10 M rows: an embedding-like corpus
-        // ran at 2 % of the N(0,1) corpus' speed). The band is small next to the corpus: every member is re-scored exactly in place
-        // (its exact score over its coarse one in the list; the others become -inf), the k-th largest exact score is found by the
-        // radix select, and only what reaches it is ranked.
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
-        const float4* q4 = reinterpret_cast<const float4*>(qhat + (int64_t)q * dim);
-        const int n4 = dim >> 2;
-        for (uint32_t i = wave; i < m; i += nw) {          // (i is wave-uniform: no divergence around the row's loads)
-            const uint2 e = list[i];
-            float sx = -INFINITY;
-            if (__uint_as_float(e.x) >= t2) sx = exact_score(master_row(master, (int64_t)e.y, dim), q4, n4, lane);
-            if (lane == 0) list[i].x = __float_as_uint(sx);
+        // ran at 2 % of the N(0,1) corpus' speed). The band is small next to the corpus: its members are compacted to the front of the
+        // list (every thread reads its <= 7 entries, then — behind a barrier — writes the members back), re-scored exactly in place
+        // (exact score over coarse score), the k-th largest exact score is found by the radix select, and only what reaches it is ranked.
+        __shared__ int wtot[16];
+        const int c = (int)((m + blockDim.x - 1) / blockDim.x);      // <= REFINE_LIST / 1024 = 7
+        uint2 mine[7];
+        bool keep[7];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint32_t i = threadIdx.x * c + j;
+            keep[j] = false;
+            if (j < c && i < m) {
+                mine[j] = list[i];
+                keep[j] = __uint_as_float(mine[j].x) >= t2;
+            }
+            cnt += keep[j] ? 1 : 0;
         }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();                                              // (also: every thread has read its chunk)
+        int pos = incl - cnt;
+        for (int w = 0; w < wave; ++w) pos += wtot[w];
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (keep[j]) list[pos++] = mine[j];
+        __syncthreads();
+        rescore(p, [&](int i) { return (int64_t)list[i].y; }, [&](int i, float sx) { list[i].x = __float_as_uint(sx); });
         __syncthreads();
         const int64_t kk2 = k < p ? k : p;
         int64_t n_gt2;
-        const uint32_t kth2 = block_kth_largest([&](int64_t i) { return f2key(__uint_as_float(list[i].x)); }, m, kk2, hist, bc, &n_gt2);
+        const uint32_t kth2 = block_kth_largest([&](int64_t i) { return f2key(__uint_as_float(list[i].x)); }, p, kk2, hist, bc, &n_gt2);
         if (threadIdx.x == 0) n_p = 0;
         __syncthreads();
         // everything above the k-th key, and EVERY entry equal to it (identical rows tie: the ranking below orders them by row id)
-        for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+        for (int i = threadIdx.x; i < p; i += blockDim.x) {
             const uint2 e = list[i];
             if (f2key(__uint_as_float(e.x)) >= kth2) {
-                const int pos = atomicAdd(&n_p, 1);
-                if (pos < REFINE_PMAX) {
-                    s_s[pos] = __uint_as_float(e.x);
-                    s_r[pos] = (int64_t)e.y;
+                const int at = atomicAdd(&n_p, 1);
+                if (at < REFINE_PMAX) {
+                    s_s[at] = __uint_as_float(e.x);
+                    s_r[at] = (int64_t)e.y;
                 }
             }
         }
@@ -276,56 +348,7 @@ __device__ __forceinline__ void refine_query(const uint2* __restrict__ cand, con
         return;
     }
     RDX_RSTAMP(4);
-    // exact re-score: one wave per candidate row
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float4* q4 = reinterpret_cast<const float4*>(qhat + (int64_t)q * dim);
-    const int n4 = dim >> 2, nw = (int)(blockDim.x >> 6);
-    if (n4 <= 256) {
-        // dim <= 1024: the query sits in registers as doubles (converted once per block, not once per candidate), a row's four
-        // 1 KiB pieces are requested together and the NEXT candidate's pieces before this one is summed. Same products, same
-        // order per lane, same butterfly as exact_score(): the same bits. (c3: k = 100, ~140 candidates per query = 9 dependent
-        // round trips to random HBM rows per wave before.)
-        int gi[4];
-        bool gv[4];
-        double qd[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            gv[u] = lane + 64 * u < n4;
-            gi[u] = gv[u] ? lane + 64 * u : n4 - 1;
-            const float4 q = q4[gi[u]];
-            qd[u][0] = gv[u] ? (double)q.x : 0.0;
-            qd[u][1] = gv[u] ? (double)q.y : 0.0;
-            qd[u][2] = gv[u] ? (double)q.z : 0.0;
-            qd[u][3] = gv[u] ? (double)q.w : 0.0;
-        }
-        auto load_row = [&](int i, float4 (&c)[4]) __attribute__((always_inline)) {
-            const MasterRow row4 = master_row(master, s_r[i], dim);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) c[u] = row4[gi[u]];
-        };
-        float4 cur[4], nxt[4];
-        if (wave < p) load_row(wave, cur);
-        for (int i = wave; i < p; i += nw) {
-            load_row(i + nw < p ? i + nw : i, nxt);   // (the last one re-reads its own row: no branch around loads)
-            double acc = 0.0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc += qd[u][0] * (double)cur[u].x;
-                acc += qd[u][1] * (double)cur[u].y;
-                acc += qd[u][2] * (double)cur[u].z;
-                acc += qd[u][3] * (double)cur[u].w;
-            }
-            const float s = (float)wave_sum(acc);
-            if (lane == 0) s_s[i] = s;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
-        }
-    } else {
-        for (int i = wave; i < p; i += nw) {
-            const float s = exact_score(master_row(master, s_r[i], dim), q4, n4, lane);
-            if (lane == 0) s_s[i] = s;
-        }
-    }
+    rescore(p, [&](int i) { return s_r[i]; }, [&](int i, float sx) { s_s[i] = sx; });
     __syncthreads();
     RDX_RSTAMP(5);
     // local -> returned row id: + row_base, or through the shard's (strictly increasing) row id map
