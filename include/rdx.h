@@ -117,6 +117,8 @@ int rdx_index_set_row_ids(rdx_index* h, int64_t first_row, const int64_t* ids, i
  * "fuse_epilogue" 0/1 (default 1): B > 128 main scan variant whose per-tile emit check rides inside the
  * first k-step of the next tile instead of interrupting the MFMA stream (speed only: +1 % at B = 1024; used when the
  * number of 64-element k-steps per row is even, the stand-alone check otherwise and with 0);
+ * "wave_layout" 0/1 (default 0; developer experiment): 1 = the fused B > 128 main scan of launches with several query tiles runs
+ * one wave per SIMD, each owning 64 rows x 256 queries (csrc/scan_w4.hpp) instead of two owning 32 x 256 (speed only);
  * "spec_tau" 0/1 (default 1): the scan threshold is taken from a rank below k of the sampled scores — an estimate of the corpus'
  * k-th score instead of a proven lower bound — and verified per query afterwards (c_k - 2E >= threshold); a query that fails
  * takes the fallback passes with the proven threshold (speed only: 2-6x fewer candidates; never results);
@@ -172,6 +174,10 @@ int rdx_enc_attention_mfma_f16(int device, const void* qkv, const int32_t* query
                                int head_dim, float scale, void* ctx, void* stream);
 int rdx_enc_add_layernorm_f16(int device, const void* a, const void* b, const void* gamma, const void* beta,
                               float eps, int64_t rows, int hidden, void* out, void* stream);
+/* rdx_enc_gelu_f16: x[i] = gelu(x[i]) IN PLACE over n fp16 values (n a multiple of 8, x 16-byte aligned): the erf form the
+ *   checkpoint's FFN uses (HF XLMRobertaIntermediate, hidden_act "gelu"), fp32 arithmetic, erf by Abramowitz & Stegun 7.1.26
+ *   (|error| <= 1.5e-7): the framework's fp16 result or its neighbour; within 1e-6 absolutely where the result underflows. */
+int rdx_enc_gelu_f16(int device, void* x, int64_t n, void* stream);
 /* rdx_enc_linear_small_f16: out[n_tokens][n_out] = act(x[n_tokens][n_in] w[n_out][n_in]^T + bias[n_out]) for at most 256 tokens (one
  *   question, a question's sub-queries): the weight matrix is read once, fp32 accumulation; act 0 = none, 1 = erf GELU (the
  *   checkpoint's). n_out a multiple of 16, n_in of 512. Larger token counts belong to the BLAS library. */

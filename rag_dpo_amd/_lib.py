@@ -71,6 +71,7 @@ SYMBOLS = {
     "rdx_l2_normalize": (_i, [_i, _vp, _i64, _i, _vp, _i, _vp]),
     "rdx_enc_attention_f16": (_i, [_i, _vp, _vp, _vp, _i64, _i, _i, ctypes.c_float, _i, _vp, _vp]),
     "rdx_enc_attention_mfma_f16": (_i, [_i, _vp, _vp, _i, _i, _i, ctypes.c_float, _vp, _vp]),
+    "rdx_enc_gelu_f16": (_i, [_i, _vp, ctypes.c_int64, _vp]),
     "rdx_enc_linear_small_f16": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rdx_enc_add_layernorm_f16": (_i, [_i, _vp, _vp, _vp, _vp, ctypes.c_float, _i64, _i, _vp, _vp]),
     "rdx_enc_embed_f16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

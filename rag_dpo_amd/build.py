@@ -27,7 +27,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdx.so")
 RESOURCES = os.path.join(HERE, "librdx.resources.json")
 SOURCES = ["rdx_api.hip"]
-HEADERS = ["rdx_common.hpp", "k_rows.hpp", "scan_kernel.hpp", "refine_kernel.hpp", "enc_kernels.hpp", "enc_small.hpp", "../../include/rdx.h"]
+HEADERS = ["rdx_common.hpp", "k_rows.hpp", "scan_kernel.hpp", "scan_w4.hpp", "refine_kernel.hpp", "enc_kernels.hpp", "enc_small.hpp", "../../include/rdx.h"]
 CHECKERS = ["isa_check.py"]   # part of the recorded hash: a library is only "fresh" if it passed THIS version of the ISA check
 
 

@@ -439,4 +439,43 @@ __global__ __launch_bounds__(256) void k_enc_attention_mfma(const _Float16* __re
     }
 }
 
+// E13 k_enc_gelu: the erf GELU of an fp16 activation IN PLACE. The FFN's first projection is a library GEMM (bias in its epilogue); its
+// [T][4096] output (168 MB at 20 K tokens) then took the framework's GELU operation: 101 us of a 248 us FFN1
+// (profiles/r04/blas_gemm_layouts.txt), and not for the bytes (3.3 TB/s): libm's erff is ~40 vector instructions per element. Here
+// erf comes from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: one reciprocal, one exp2, a degree-5 polynomial):
+//   z = x / sqrt 2, t = 1 / (1 + p |z|), q = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) e^(-z^2) = erfc(|z|)
+//   gelu(x) = x/2 (1 + erf z) = x/2 (2 - q)  for z >= 0,  x/2 q  for z < 0
+// fp32 arithmetic, one rounding to fp16. Against torch.nn.functional.gelu on fp16: the same fp16 value or its neighbour wherever
+// |gelu| >= 6e-5, within 1e-6 absolutely in the underflowing negative tail (tests/test_embedding_provider.py), NaN -> NaN.
+// HBM-bound target: 4 B per element. grid = min(n / 2048, 2048) workgroups of 256 lanes, 16 B per lane per step.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_enc_gelu(_Float16* __restrict__ x, int64_t n8) {
+    // two elements per vector instruction where the ISA has one (v_pk_fma_f32 / v_pk_mul_f32): the kernel is bound by the vector ALU
+    const f32x2 c5 = {1.061405429f, 1.061405429f}, c4 = {-1.453152027f, -1.453152027f}, c3 = {1.421413741f, 1.421413741f},
+                c2 = {-0.284496736f, -0.284496736f}, c1 = {0.254829592f, 0.254829592f}, one = {1.f, 1.f}, pp = {0.3275911f, 0.3275911f};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        half8 v = *reinterpret_cast<const half8*>(x + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2 f = {(float)v[j], (float)v[j + 1]};
+            const f32x2 h = 0.5f * f, z = 0.70710678118654752f * f;
+            const f32x2 az = {__builtin_fabsf(z[0]), __builtin_fabsf(z[1])};
+            const f32x2 d = __builtin_elementwise_fma(pp, az, one);
+            const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            f32x2 pl = __builtin_elementwise_fma(c5, t, c4);
+            pl = __builtin_elementwise_fma(pl, t, c3);
+            pl = __builtin_elementwise_fma(pl, t, c2);
+            pl = __builtin_elementwise_fma(pl, t, c1);
+            const f32x2 e2 = -1.4426950408889634f * z * z;
+            const f32x2 ex = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};   // exp2 of -inf = 0
+            const f32x2 q = pl * t * ex;                                                        // erfc(|z|)
+            const f32x2 w = {z[0] >= 0.f ? 2.0f - q[0] : q[0], z[1] >= 0.f ? 2.0f - q[1] : q[1]};   // (NaN: the comparison is false -> NaN * NaN)
+            const f32x2 r = h * w;
+            v[j] = (_Float16)r[0];
+            v[j + 1] = (_Float16)r[1];
+        }
+        *reinterpret_cast<half8*>(x + i * 8) = v;
+    }
+}
+
 }  // namespace rdx

@@ -26,6 +26,7 @@
 #include "k_rows.hpp"
 #include "refine_kernel.hpp"
 #include "scan_kernel.hpp"
+#include "scan_w4.hpp"
 
 using namespace rdx;
 
@@ -139,7 +140,7 @@ struct rdx_index {
     std::mutex mu;
 
     // options
-    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 1, force_bn = 0;
+    int force_exact = 0, force_fast = 0, profile = 0, sib_sync = 0, sib_lag = 6, retry = 1, xcd_balance = 1, fuse_epilogue = 1, force_bn = 0, wave_layout = 0;
     int half_boot = 1;       // option: 129..256 queries take their threshold sample as two 128-query tiles per sampled corpus tile
     int small_scan = 1;      // option: k_scan_small (split-K over all rows) as the main scan of small launches
     int split_boot = 1;      // option: k_boot (K loop split over the waves) for the threshold bootstrap of small launches
@@ -376,6 +377,7 @@ extern "C" int rdx_index_set_option(rdx_index* h, const char* name, int64_t valu
     else if (n == "sib_sync") h->sib_sync = value != 0;
     else if (n == "retry") h->retry = value != 0;
     else if (n == "fuse_epilogue") h->fuse_epilogue = value != 0;
+    else if (n == "wave_layout") h->wave_layout = value == 1 ? 1 : 0;
     else if (n == "fuse_finish") h->fuse_finish = value != 0;
     else if (n == "split_boot") h->split_boot = value != 0;
     else if (n == "small_scan") h->small_scan = value != 0;
@@ -886,6 +888,20 @@ extern "C" int rdx_enc_layernorm_rows_f16(int device, const void* s, const void*
 }
 
 
+extern "C" int rdx_enc_gelu_f16(int device, void* x, int64_t n, void* stream) {
+    if (n < 0 || n % 8) return fail(RDX_ERR_INVALID, "rdx_enc_gelu_f16: n must be a non-negative multiple of 8");
+    if (n == 0) return RDX_OK;
+    if (!x || ((uintptr_t)x & 15)) return fail(RDX_ERR_INVALID, "rdx_enc_gelu_f16: x must be a 16-byte aligned device pointer");
+    if (device < 0 || device >= 64) return fail(RDX_ERR_INVALID, "rdx_enc_gelu_f16: device out of range");
+    HIP_TRY(hipSetDevice(device));
+    const int64_t n8 = n / 8;
+    const unsigned grid = (unsigned)std::min<int64_t>((n8 + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_enc_gelu, dim3(grid), dim3(256), 0, (hipStream_t)stream, (_Float16*)x, n8);
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
+
 extern "C" int rdx_l2_normalize(int device, const float* in, int64_t n, int dim, float* out, int space, void* stream) {
     if (n < 0 || (n > 0 && (!in || !out))) return fail(RDX_ERR_INVALID, "rdx_l2_normalize: bad argument");
     RDX_TRY(check_dim(dim));
@@ -943,6 +959,16 @@ static int launch_scan(rdx_index* h, const ScanParams& p, int grid, hipStream_t 
     return RDX_OK;
 }
 
+// developer experiment (option "wave_layout" = 1): the B > 128 fused main scan with one wave per SIMD, csrc/scan_w4.hpp
+static int launch_scan_w4(rdx_index* h, const ScanParams& p, int grid, hipStream_t st) {
+    const size_t lds = (size_t)RING_SLOTS * 256 * BK * 2 + 256 * 8 + 256 * 64;   // ring + counters + thresholds + the emit path's staging rows
+    void (*kern)(const ScanParams) = p.allow ? k_scan_w4<true> : k_scan_w4<false>;
+    RDX_TRY(ensure_dynamic_lds(h, (const void*)kern, lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
+    HIP_TRY(hipGetLastError());
+    return RDX_OK;
+}
+
 template <int EPI>
 static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, int grid, hipStream_t st) {
     // NTT (5th template argument): one query tile -> every corpus byte is read by exactly one workgroup -> non-temporal loads
@@ -963,6 +989,7 @@ static int launch_scan_bn(rdx_index* h, int bn, bool res, const ScanParams& p, i
             if ((p.ksteps & 1) == 0 && h->fuse_epilogue) {
                 if (p.sib) return launch_scan<256, EPI, false, true, false, true>(h, p, grid, st);
                 if (p.nqt == 1) return launch_scan<256, EPI, false, false, true, true>(h, p, grid, st);
+                if (h->wave_layout == 1 && p.tile_stride == 1) return launch_scan_w4(h, p, grid, st);
                 return launch_scan<256, EPI, false, false, false, true>(h, p, grid, st);
             }
         }

@@ -130,6 +130,7 @@ class _PackedEncoder:
             self.stage_fpb_o = int(os.environ.get("RDX_ENC_FPB_O", self.STAGE_FPB_O))
             self.stage_fpb_f2 = int(os.environ.get("RDX_ENC_FPB_F2", self.STAGE_FPB_F2))
 
+    MFMA_MIN_TOKENS = int(os.environ.get("RDX_ENC_MFMA_MIN", "1024"))   # question batches of at least this many tokens take the MFMA attention kernel too (developer knob)
     FUSED_MAX_TOKENS = 64       # up to here the VALU attention kernel (written for questions); beyond, the MFMA kernel (long_attention)
     long_attention = os.environ.get("RDX_ENC_LONG_ATTN", "mfma") != "torch"   # developer: "torch" = scatter -> SDPA -> gather for texts beyond 64 tokens
 
@@ -141,6 +142,19 @@ class _PackedEncoder:
         if rc:
             raise RuntimeError("rdx_enc_add_layernorm_f16: " + self._last_error())
         return out
+
+    # The FFN's erf GELU is the framework's operation (bit-equal to the module forward). librdx's in-place kernel (E13, rdx_enc_gelu_f16: the
+    # same values to within one fp16 ulp) is 81 against 101 us behind a 148 us FFN1 GEMM at 20 K tokens, and NOTHING in the pipeline: c5
+    # encode 15.71 / 15.73 against 15.87 / 15.80 ms, ingest 3 429 against 3 435 chunks/s (profiles/r04/gelu_inplace_ab.txt) — opt-in only.
+    inplace_gelu = os.environ.get("RDX_ENC_GELU", "torch") == "inplace"
+
+    def _gelu(self, x: torch.Tensor) -> torch.Tensor:
+        """erf GELU of the FFN's first projection: the framework's, or (RDX_ENC_GELU=inplace) librdx's in-place kernel E13"""
+        if not self.inplace_gelu or x.numel() % 8 or not x.is_contiguous():
+            return torch.nn.functional.gelu(x)
+        if self._lib.rdx_enc_gelu_f16(x.device.index or 0, x.data_ptr(), x.numel(), torch.cuda.current_stream(x.device).cuda_stream):
+            raise RuntimeError("rdx_enc_gelu_f16: " + self._last_error())
+        return x
 
     # up to here the projections are librdx's weight-streaming kernel (rdx_enc_linear_small_f16) instead of the BLAS library's GEMM. Measured
     # (tools/enc_small_sweep.py, graph replay, XLM-R-large): one question (32 padded tokens) 1.71 -> 1.36 ms; at 64 tokens the two are
@@ -257,7 +271,7 @@ class _PackedEncoder:
                 x = self._add_ln(self._linear(self._linear(x, inter.weight, inter.bias, gelu=True), out.weight, out.bias), x, ln2)
             else:
                 x = self._add_ln(dense_o(ctx), x, ln1)
-                x = self._add_ln(out(F.gelu(inter(x))), x, ln2)
+                x = self._add_ln(out(self._gelu(inter(x))), x, ln2)
         return x.to(torch.float32)
 
     def _replay(self, key, host: dict, to_dev, max_len: int, unpack=None):
@@ -303,6 +317,14 @@ class _PackedEncoder:
 
     _ORDER = ("pk_tok", "pk_pos", "pk_first", "pk_tfirst", "pk_tlen")
 
+    @staticmethod
+    def _query_blocks(first: np.ndarray, lens: np.ndarray) -> torch.Tensor:
+        """The MFMA attention kernel's work units: one per 64 queries of a text, {first token, length, first query, 0}."""
+        nb = (lens + 63) // 64
+        tix = np.repeat(np.arange(len(lens), dtype=np.int64), nb)
+        q0 = (np.arange(int(nb.sum()), dtype=np.int64) - np.repeat(np.cumsum(nb) - nb, nb)) * 64
+        return torch.from_numpy(np.stack([first[tix], lens[tix], q0, np.zeros_like(q0)], axis=1).astype(np.int32))
+
     @torch.no_grad()
     def cls(self, ids: torch.Tensor, lens: np.ndarray, to_dev) -> torch.Tensor:
         """ids: [B][S] int64 on the host, right-padded; lens[b] = tokens of text b (>= 1). -> fp32 [B][hidden] CLS rows on the device.
@@ -322,12 +344,10 @@ class _PackedEncoder:
             host["pk_tfirst"] = torch.from_numpy(np.repeat(first, lens).astype(np.int32))
             host["pk_tlen"] = torch.from_numpy(np.repeat(lens, lens).astype(np.int32))
             max_len = int(lens.max())
-            if max_len > self.FUSED_MAX_TOKENS:
-                # the corpus side: chunk texts of hundreds of tokens. One work unit per 64 queries of a text: {first token, length, first query}
-                nb = (lens + 63) // 64
-                tix = np.repeat(np.arange(B, dtype=np.int64), nb)
-                q0 = (np.arange(int(nb.sum()), dtype=np.int64) - np.repeat(np.cumsum(nb) - nb, nb)) * 64
-                host["pk_qb"] = torch.from_numpy(np.stack([first[tix], lens[tix], q0, np.zeros_like(q0)], axis=1).astype(np.int32))
+            if max_len > self.FUSED_MAX_TOKENS or (self.long_attention and T >= self.MFMA_MIN_TOKENS):
+                # the corpus side (chunk texts of hundreds of tokens) and large batches of questions (1024 questions: 39 us per layer
+                # against the VALU kernel's 57, profiles/r04/attention_mfma_bench.txt): the MFMA kernel, one work unit per 64 queries
+                host["pk_qb"] = self._query_blocks(first, lens)
             if self.graphs and B <= self.SMALL_TEXTS and max_len <= self.FUSED_MAX_TOKENS:
                 # (<= 32 tokens run the stage kernels: their cost follows the activation rows a workgroup stages, so the canonical shapes
                 #  are 8, 16, 24 and 32 tokens — a typical 20-token question pays for 24 rows, not 32)
@@ -372,6 +392,12 @@ class _PackedEncoder:
                           "pk_first": host["pk_first"],
                           "pk_tfirst": torch.from_numpy(np.concatenate([host["pk_tfirst"].numpy(), np.arange(T, Tp, dtype=np.int32)])),
                           "pk_tlen": torch.from_numpy(np.concatenate([host["pk_tlen"].numpy(), np.ones(extra, dtype=np.int32)]))}
+                if "pk_qb" in host:
+                    # (B + extra work units; `extra` moves with T inside one canonical shape, so the list is filled up to B + g units
+                    #  with repeats of the last one: the same rows written twice with the same values)
+                    qb = self._query_blocks(np.concatenate([first, np.arange(T, Tp, dtype=np.int64)]),
+                                            np.concatenate([lens, np.ones(extra, dtype=np.int64)]))
+                    padded["pk_qb"] = torch.cat([qb, qb[-1:].expand(B + g - qb.shape[0], 4)]).contiguous()
                 big = [k_ for k_ in self._graph if k_[0] == "large"]
                 key = ("large", B, Tp, lb)
                 if key not in self._graph and len(big) >= self.MAX_LARGE_GRAPHS:
@@ -379,7 +405,7 @@ class _PackedEncoder:
                 out = self._replay(key, padded, to_dev, lb)
                 if out is not None:
                     return out
-                return self._fused_forward(*(to_dev(n, padded[n]) for n in self._ORDER), lb)
+                return self._fused_forward(*(to_dev(n, padded[n]) for n in self._ORDER), lb, to_dev("pk_qb", padded["pk_qb"]) if "pk_qb" in padded else None)
             elif self.graphs is True:
                 nqb = int(host["pk_qb"].shape[0]) if "pk_qb" in host else 0
                 out = self._replay((B, T, max_len, nqb), host, to_dev, max_len)   # (the longest text sizes the attention's LDS window: part of the shape)

@@ -533,6 +533,52 @@ def test_long_texts_take_the_packed_forward_with_the_mfma_attention():
 
 
 @pytest.mark.gpu
+def test_encoder_gelu_in_place_vs_the_framework_operation():
+    """rdx_enc_gelu_f16 (E13: erf by Abramowitz & Stegun 7.1.26 in fp32, one rounding to fp16) against torch.nn.functional.gelu on fp16
+    AND against the fp64 definition: random values across both branches, every fp16 bit pattern, infinities, NaN -> NaN. Tolerance: the
+    neighbouring fp16 value (|diff| <= one fp16 ulp of the reference) or 1e-6 absolutely (the underflowing negative tail), whichever is
+    larger. Of N(0, 9) inputs ~94 % come out as the framework's very fp16 value (the rest are its neighbour: the negative side, where
+    gelu = x/2 erfc and 1.5e-7 of erf is a visible fraction of the result); the sign of a zero result is left open (the framework's own
+    small- and large-tensor kernels disagree about gelu(-0.0))."""
+    import torch
+    from rag_dpo_amd import _lib
+    L = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def check(x):
+        d = x.cuda()
+        want = torch.nn.functional.gelu(d)
+        got = d.clone()
+        assert L.rdx_enc_gelu_f16(0, got.data_ptr(), got.numel(), st) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        nan = torch.isnan(want)
+        assert bool((torch.isnan(got) == nan).all())
+        w64, g64, x64 = want.double()[~nan], got.double()[~nan], d.double()[~nan]
+        inf = torch.isinf(w64)
+        assert bool((g64[inf] == w64[inf]).all())
+        w64, g64, x64 = w64[~inf], g64[~inf], x64[~inf]
+        assert bool(torch.isfinite(g64).all())
+        exact = 0.5 * x64 * (1 + torch.erf(x64 * 2 ** -0.5))
+        ulp = torch.clamp(2.0 ** (torch.floor(torch.log2(torch.clamp(w64.abs(), min=2.0 ** -14))) - 10), min=2.0 ** -24)
+        tol = 1.000001 * torch.clamp(ulp, min=1e-6)
+        assert bool(((g64 - w64).abs() <= tol).all()), float(((g64 - w64).abs() / tol).max())
+        fin = torch.isfinite(exact) & (exact.abs() < 65504)
+        assert bool(((g64 - exact).abs()[fin] <= tol[fin]).all())
+        return float((g64 == w64).double().mean())
+    for n in (8, 4096 * 33, 20_003 * 8):
+        x = (torch.randn(n, generator=g) * 3).half()
+        x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, -65504.0, 6e-8, -10.0]).half()
+        same = check(x)
+        assert n == 8 or same >= 0.9, (n, same)
+    allv = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16).view(torch.float16)     # every fp16 bit pattern
+    check(allv.repeat(64))                                          # (large enough for the framework's vectorised kernel)
+    got = allv.cuda()
+    assert L.rdx_enc_gelu_f16(0, got.data_ptr(), 12, st) != 0
+    assert L.rdx_enc_gelu_f16(0, got.data_ptr() + 2, 8, st) != 0
+
+
+@pytest.mark.gpu
 def test_encoder_embed_and_last_layernorm_kernels():
     """rdx_enc_embed_f16 = the module's embedding sum (two fp16 adds in its order: bit-equal to torch); rdx_enc_layernorm_rows_f16 = torch's
     fp16 LayerNorm widened to fp32 (within one fp16 ulp of the fp32 LayerNorm)."""
@@ -598,6 +644,36 @@ def test_single_question_forward_vs_module_forward():
         for p in (fast, mod16, mod32):
             if p is not None:
                 p.unload()
+
+
+@pytest.mark.gpu
+def test_large_question_batches_replay_one_canonical_graph():
+    """BASELINE config 5's encode leg: a large batch of questions is padded to the next multiple of 1024 tokens with one-token dummy
+    texts and replays ONE captured graph per canonical shape (MFMA attention: a work-unit list of fixed size); batches whose real token
+    counts differ inside the same shape share it. Each batch against the eager forward of the same weights (|1 - cos| <= 1e-5)."""
+    import torch
+    from rag_dpo_amd import synth
+    from rag_dpo_amd.embedding_provider import EmbeddingProvider
+    fast = EmbeddingProvider(model_name="random-init:mid", device="cuda:0", dtype=torch.float16, batch_size=256).load()
+    eager = EmbeddingProvider(model_name="random-init:mid", device="cuda:0", dtype=torch.float16, batch_size=256)
+    eager.encoder_graphs = False
+    eager.load()
+    assert fast._packed.large_graphs and fast._packed.long_attention
+    seen_tokens = set()
+    for seed in (1, 2, 3, 4, 5):
+        texts = synth.query_texts(90, seed=seed)                   # ~20 tokens each: ~1.8 K tokens -> the 2048-token shape
+        got = fast.embed_device(texts).clone()
+        seen_tokens.add(fast.last_encode_stats["tokens_real"])
+        assert 1024 < fast.last_encode_stats["tokens_real"] <= 2048
+        ref = eager.embed_device(texts)
+        cos = torch.nn.functional.cosine_similarity(got.double(), ref.double(), dim=1)
+        assert float((1 - cos).abs().max()) <= 1e-5, (seed, float((1 - cos).abs().max()))
+    assert len(seen_tokens) >= 3                                   # different real token counts ...
+    large = [k for k in fast._packed._graph if k[0] == "large"]
+    assert len(large) == 1 and large[0][:3] == ("large", 90, 2048), large                        # ... one graph
+    assert not eager._packed._graph
+    fast.unload()
+    eager.unload()
 
 
 @pytest.mark.gpu

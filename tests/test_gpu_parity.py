@@ -191,6 +191,26 @@ def test_fused_epilogue_variant(eng, oracle, fused):
     ix.close()
 
 
+@pytest.mark.parametrize("rows,dim,b", [(140_001, 256, 600), (70_000, 1024, 1000)])
+def test_one_wave_per_simd_layout(eng, oracle, rows, dim, b):
+    """developer option wave_layout = 1 (csrc/scan_w4.hpp): the B > 128 fused main scan with 4 waves per workgroup, each owning 64
+    rows x 256 queries (256 pinned accumulators, inline-asm MFMAs, the rare emit path staged through LDS) — same candidates, so the
+    same answers: several tiles per stream, ragged last tiles (225 and 112 rows: a wave with 33 rows, waves with none), three and
+    four query tiles (the last one partly filled; launches of at most two tiles take 128-query workgroups), a row bitmap, against
+    the oracle; the candidate count equals the shipped kernel's"""
+    corpus = synth.make_corpus(rows, dim)
+    q = synth.make_queries(b, dim, corpus)
+    ix = _index(eng, corpus, force_fast=1, wave_layout=1)
+    st = _check(oracle, ix, corpus, q, 10, expect_path=0)
+    assert st["exact_queries"] == 0
+    allow = np.random.default_rng(1).random(corpus.shape[0]) < 0.4
+    _check(oracle, ix, corpus, q, 20, allow, expect_path=0)
+    e1 = _check(oracle, ix, corpus, q, 10, expect_path=0)["emitted"]
+    ix.set_option("wave_layout", 0)
+    assert _check(oracle, ix, corpus, q, 10, expect_path=0)["emitted"] == e1
+    ix.close()
+
+
 def test_xcd_shares_ignore_idle_workgroups(eng):
     """nq = 600 -> three query tiles: 32 workgroups per XCD = 10 streams x 3 + 2 idle ones, which return before they stamp
     their times. The XCD re-weighting must skip them (their stamp slots are stale memory): shares stay near an eighth and

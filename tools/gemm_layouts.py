@@ -1,6 +1,7 @@
 """Developer: the encoder's four projection shapes through the BLAS library in its layouts — F.linear(x, W[N][K]) (what the module calls),
 addmm with a pre-transposed weight W^T[K][N], and the fused-GELU epilogue variants torch exposes — TFLOP/s by HIP events, random data."""
-import sys, torch
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 20480
 dev = "cuda:0"
 g = torch.Generator(device=dev); g.manual_seed(0)
@@ -22,6 +23,13 @@ for N, K in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
          "matmul W^T (no bias)": bench(lambda: x @ wt)}
     if N == 4096:
         r["linear + gelu (erf, two kernels)"] = bench(lambda: torch.nn.functional.gelu(torch.nn.functional.linear(x, w, b)))
+        from rag_dpo_amd import _lib
+        L = _lib.load()
+        def lin_gelu_inplace():
+            y = torch.nn.functional.linear(x, w, b)
+            L.rdx_enc_gelu_f16(0, y.data_ptr(), y.numel(), torch.cuda.current_stream().cuda_stream)
+            return y
+        r["linear + librdx gelu in place (E13)"] = bench(lin_gelu_inplace)
         try:
             r["_addmm_activation gelu (tanh epilogue)"] = bench(lambda: torch._addmm_activation(b, x, wt, use_gelu=True))
         except Exception as e:
