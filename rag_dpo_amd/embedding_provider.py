@@ -130,7 +130,12 @@ class _PackedEncoder:
             self.stage_fpb_o = int(os.environ.get("RDX_ENC_FPB_O", self.STAGE_FPB_O))
             self.stage_fpb_f2 = int(os.environ.get("RDX_ENC_FPB_F2", self.STAGE_FPB_F2))
 
-    MFMA_MIN_TOKENS = int(os.environ.get("RDX_ENC_MFMA_MIN", "1024"))   # question batches of at least this many tokens take the MFMA attention kernel too (developer knob)
+    # Question batches (every text <= FUSED_MAX_TOKENS) of at least this many tokens would take the MFMA attention kernel too. Alone it
+    # wins (1024 questions: 39 us per layer against the VALU kernel's 57, profiles/r04/attention_mfma_bench.txt); inside config 5's
+    # pipeline it LOSES: the encode of batch i+1 runs beside the MFMA-bound search of batch i, and a kernel on the vector ALU fills what
+    # the scan leaves idle while a second MFMA kernel queues for the same pipes (encode 16.1 / 16.0 against 15.4 / 15.4 ms, step 31.96 /
+    # 31.76 against 31.15 / 31.24 ms, profiles/r04/c5_n1_bench.json, c5_mfma_attention_for_questions_n1_bench.json). Default: never; developer knob RDX_ENC_MFMA_MIN.
+    MFMA_MIN_TOKENS = int(os.environ.get("RDX_ENC_MFMA_MIN", str(1 << 40)))
     FUSED_MAX_TOKENS = 64       # up to here the VALU attention kernel (written for questions); beyond, the MFMA kernel (long_attention)
     long_attention = os.environ.get("RDX_ENC_LONG_ATTN", "mfma") != "torch"   # developer: "torch" = scatter -> SDPA -> gather for texts beyond 64 tokens
 
@@ -345,8 +350,8 @@ class _PackedEncoder:
             host["pk_tlen"] = torch.from_numpy(np.repeat(lens, lens).astype(np.int32))
             max_len = int(lens.max())
             if max_len > self.FUSED_MAX_TOKENS or (self.long_attention and T >= self.MFMA_MIN_TOKENS):
-                # the corpus side (chunk texts of hundreds of tokens) and large batches of questions (1024 questions: 39 us per layer
-                # against the VALU kernel's 57, profiles/r04/attention_mfma_bench.txt): the MFMA kernel, one work unit per 64 queries
+                # the corpus side (chunk texts of hundreds of tokens; and large question batches when MFMA_MIN_TOKENS says so): the MFMA
+                # kernel, one work unit per 64 queries
                 host["pk_qb"] = self._query_blocks(first, lens)
             if self.graphs and B <= self.SMALL_TEXTS and max_len <= self.FUSED_MAX_TOKENS:
                 # (<= 32 tokens run the stage kernels: their cost follows the activation rows a workgroup stages, so the canonical shapes

@@ -647,9 +647,10 @@ def test_single_question_forward_vs_module_forward():
 
 
 @pytest.mark.gpu
-def test_large_question_batches_replay_one_canonical_graph():
+@pytest.mark.parametrize("mfma_min", [None, 1024])
+def test_large_question_batches_replay_one_canonical_graph(mfma_min):
     """BASELINE config 5's encode leg: a large batch of questions is padded to the next multiple of 1024 tokens with one-token dummy
-    texts and replays ONE captured graph per canonical shape (MFMA attention: a work-unit list of fixed size); batches whose real token
+    texts and replays ONE captured graph per canonical shape; batches whose real token
     counts differ inside the same shape share it. Each batch against the eager forward of the same weights (|1 - cos| <= 1e-5)."""
     import torch
     from rag_dpo_amd import synth
@@ -659,6 +660,8 @@ def test_large_question_batches_replay_one_canonical_graph():
     eager.encoder_graphs = False
     eager.load()
     assert fast._packed.large_graphs and fast._packed.long_attention
+    if mfma_min is not None:                                       # (developer knob: the MFMA attention kernel for question batches too —
+        fast._packed.MFMA_MIN_TOKENS = mfma_min                    #  a work-unit list of fixed size rides in the canonical shape)
     seen_tokens = set()
     for seed in (1, 2, 3, 4, 5):
         texts = synth.query_texts(90, seed=seed)                   # ~20 tokens each: ~1.8 K tokens -> the 2048-token shape

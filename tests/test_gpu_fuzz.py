@@ -13,6 +13,7 @@ def test_random_shapes_match_oracle(oracle):
     import os
     rng = np.random.default_rng(int(os.environ.get("RDX_FUZZ_SEED", "20261004")))   # other seeds: a longer hunt by hand
     total = int(os.environ.get("RDX_FUZZ_CASES", "36"))
+    rng_w = np.random.default_rng([int(os.environ.get("RDX_FUZZ_SEED", "20261004")), 77])   # (its own stream: the standing seeds keep their cases)
     dims = [64, 128, 192, 256, 320, 768, 1024]
     n_cases = 0
     for case in range(total):
@@ -71,6 +72,8 @@ def test_random_shapes_match_oracle(oracle):
             opts["half_boot"] = 0       # (default 1: 129..256 queries sample their threshold as two 128-query tiles per corpus tile)
         if rng.random() < 0.3:
             opts["spread_boot"] = 0     # (default 1: the threshold sample of > 64 queries is every div-th 32-row block, not every div-th tile)
+        if rng_w.random() < 0.4:
+            opts["wave_layout"] = 1     # (default 0: developer variant of the B > 128 main scan, one wave per SIMD; csrc/scan_w4.hpp)
         for name, v in opts.items():
             ix.set_option(name, v)
         es, er, ec = oracle.cosine_topk(oracle.normalize_rows(corpus), q, k, allow)
