@@ -17,6 +17,9 @@
 // segments and counters, emit check of a tile fused into the first k-step of the next one (even number of k-steps: the host checks).
 // Vector-memory order of a wave per k-step (the counted waits depend on it): 4 corpus loads (k sub-step 0 registers) | barrier |
 // 8 DMA pieces | 4 corpus loads (k sub-step 1 registers) = 16 operations.
+//
+// Measured (profiles/r04/c4_wave_layout_1x.txt): -7 % at 10 M rows x 1024 queries, -20 % on a 2 M-row shard; LDS waits halved, clock
+// 1.60 -> 1.88 GHz, MFMA pipe busy 73 -> 47 % of the cycles. Kept as a measured variant, not as the product path.
 #pragma once
 #include <utility>
 
@@ -27,9 +30,6 @@
 #endif
 #ifndef W4_BURST
 #define W4_BURST 0  // 1: the 8 DMA pieces of a step go out together right behind the barrier (as k_scan does) instead of one per MFMA group
-#endif
-#ifndef W4_DRAIN
-#define W4_DRAIN 0  // 1 (debug): every counted wait is a full drain
 #endif
 #ifndef W4_PD
 #define W4_PD 2     // query-fragment groups read ahead
@@ -63,11 +63,10 @@ __device__ __forceinline__ void wait_vmcnt_keep8(half8 (&a)[8]) {
 // the MFMA that wrote it (blocks are visited round-robin, 8 groups of 8 MFMAs per k sub-step); the A/B operands come from memory
 // instructions whose completion is waited for (s_waitcnt), never from a vector ALU instruction right in front.
 #ifndef W4_BUILTIN
-#define W4_BUILTIN 0
+#define W4_BUILTIN 0   // 1 (debug): the compiler's builtin instead — slow (accumulator traffic), but hazard-free by the compiler's own rules: the
+                       // reference build that told a scheduling bug of the asm form (vector zeroing of accumulators) from a logic bug
 #endif
-#ifndef W4_WARNOP
-#define W4_WARNOP 0
-#endif
+
 __device__ __forceinline__ void mfma_acc(f32x4& c, const half8& a, const half8& b) {
 #if W4_BUILTIN
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(256) void k_scan_w4(const ScanParams p) {
         auto step = [&](auto fuse_tag, half8 (&af)[8], int s, int it_prev) __attribute__((always_inline)) {
             constexpr bool FUSE = decltype(fuse_tag)::value;
             // this step's corpus fragments were issued two steps ago; the 16 operations of the step in between stay in flight
-            wait_vmcnt_keep8<W4_DRAIN ? 0 : V>(af);
+            wait_vmcnt_keep8<V>(af);
             const char* st = smem + slot_c * B_BYTES;
             const char* stn = smem + ((slot_c + 1) & 3) * B_BYTES;
             const bool more = s + 2 < total;
@@ -286,7 +285,7 @@ __global__ __launch_bounds__(256) void k_scan_w4(const ScanParams p) {
                     // image s+1: my pieces went out during step s-2; since then 4 (its last corpus loads) + 16 (step s-1) + 4 (the
                     // first corpus loads of this step) operations. Behind the barrier every wave has left step s-1: its slot is refilled.
                     __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W4_DRAIN ? 0 : NA + V) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + V) : "memory");
                     __builtin_amdgcn_s_barrier();
                     if (W4_BURST) {
 #pragma unroll
@@ -316,7 +315,6 @@ __global__ __launch_bounds__(256) void k_scan_w4(const ScanParams p) {
                         else mfma_acc(acc[m][n], av, bf[g % NBUF][j]);
                         if (m == 0) {
                             __builtin_amdgcn_sched_barrier(0);
-                            if (W4_WARNOP) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");   // (debug: nothing overwrites a register right behind an MFMA)
                             if (j == 0) {
                                 if (g + PD < NG) load_group(st, g + PD, bf[(g + PD) % NBUF]);
                                 else load_group(stn, g + PD - NG, bf[(g + PD) % NBUF]);   // first groups of step s+1 (behind the barrier)
