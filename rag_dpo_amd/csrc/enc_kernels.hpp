@@ -308,7 +308,9 @@ namespace rdx {
 constexpr int ATT_KT = 32;
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-__global__ __launch_bounds__(256) void k_enc_attention_mfma(const _Float16* __restrict__ qkv, const int32_t* __restrict__ qb, int heads, float scale_log2,
+// (five waves per SIMD: the kernel is bound by the latency of a tile's dependent chain, and left alone the compiler takes 98 + 16
+//  registers = four waves; it fits 90 without a spill. Six waves spill 37.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void k_enc_attention_mfma(const _Float16* __restrict__ qkv, const int32_t* __restrict__ qb, int heads, float scale_log2,
                                                             _Float16* __restrict__ ctx) {
     __shared__ __attribute__((aligned(16))) _Float16 ks[2][ATT_KT * 64];
     __shared__ __attribute__((aligned(16))) _Float16 vs[2][ATT_KT * 64];
