@@ -159,6 +159,17 @@ def cpu_baseline_and_recall(shard: HipShard, queries: torch.Tensor, wl: dict, to
     return cpu, rec
 
 
+INFINITY_CACHE_BYTES = 256 * 2 ** 20
+
+
+def _bytes_source(bytes_per_launch: float) -> str:
+    """where a launch's algorithmic bytes come from when every step reads the same buffers again: a working set below the 256 MB
+    Infinity Cache stays there between steps, and a fraction "of 8 TB/s" is then a yardstick, not an HBM measurement"""
+    if bytes_per_launch <= INFINITY_CACHE_BYTES:
+        return "Infinity-Cache resident between steps (working set <= 256 MB): frac is against the HBM yardstick, the bytes do not come from HBM"
+    return "HBM (working set larger than the 256 MB Infinity Cache)"
+
+
 def run_other_config(name: str, device, steps: int, warmup: int) -> dict:
     """One more BASELINE config in the same process, AFTER the timed region of the line's own workload (never inside it): its own
     index, `steps` timed searches with the corpus and the queries resident, the dominant kernel timed by librdx's HIP events on the
@@ -216,6 +227,7 @@ def run_other_config(name: str, device, steps: int, warmup: int) -> dict:
         exact = bool((gr == er).all() and (gs == es).all() and (gc == ec).all())
         return {"workload": wl["desc"], "steps": steps, "ms_per_step": round(ms_step, 4), "queries_per_s": round(B / ms_step * 1e3, 1),
                 "main_kernel": kernel, "main_kernel_ms": round(kern_ms, 4), "bound": bound, "frac": round(frac, 4),
+                "bytes_source": _bytes_source(by),
                 "ids_bit_exact_vs_oracle": exact, "oracle_check": f"{nchk} queries x {sample} rows" + ("" if sample == rows else " (bitmap-selected sample)"),
                 "emitted_per_query": round(stats["emitted"] / max(1, B), 1), "retried_queries": stats["retried_queries"],
                 "exact_fallback_queries": stats["exact_queries"], "build_and_run_s": round(time.time() - t0, 2)}
@@ -593,6 +605,7 @@ def main():
                                    "profile=3, averaged over the timed steps of THIS run; no event records on the stream"),
                          "launch_rows": n_local, "launch_queries": B, "flops_per_launch": flops,
                          "bytes_read_per_launch": bytes_, "bytes_read_is": "fp16 scan copy once + fp16 query images (what the kernel loads)",
+                         "bytes_source": _bytes_source(bytes_),
                          "bytes_survey_8d_per_launch": bytes_8d, "bytes_survey_8d_is": f"N_local*d*{int(s_in)} + B*d*4 + B*k*8 (SURVEY.md §8d)",
                          "hbm_frac_of_8TBs": round(bytes_ / sec / 1e9 / PEAK_HBM_GBS, 4),
                          "hbm_frac_of_8TBs_on_survey_8d_bytes": round(bytes_8d / sec / 1e9 / PEAK_HBM_GBS, 4),

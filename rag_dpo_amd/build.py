@@ -132,6 +132,12 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
         if bad:
             raise RuntimeError("scan kernels spill registers — refused (inline-asm loads may be in flight to a spilled register):\n" +
                                "\n".join(f"  {k}: {v}" for k, v in bad.items()))
+        # kernels that are given an occupancy target (amdgpu_waves_per_eu: the latency-bound attention kernel E12) pay for a miss
+        # silently, in scratch traffic: refused as well (a variant build with extra flags may spill: it is nobody's product)
+        slow = {k: v for k, v in res.items() if "k_enc_attention_mfma" in k and (v.get("spill_vgprs", 0) or v.get("scratch_bytes", 0))}
+        if slow and not extra_flags:
+            raise RuntimeError("k_enc_attention_mfma no longer fits its occupancy target without spilling — refused:\n" +
+                               "\n".join(f"  {k}: {v}" for k, v in slow.items()))
         isa = check_isa(work)
         final_tmp = (out or LIB) + ".tmp"
         shutil.move(tmp, final_tmp)
