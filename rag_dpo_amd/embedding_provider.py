@@ -291,6 +291,7 @@ class _PackedEncoder:
             if self._seen[key] < 2:
                 return None
             while len(self._graph) >= self.MAX_GRAPHS:
+                torch.cuda.current_stream(self.layers[0][0].device).synchronize()   # (its last replay may still run: its pool is freed with it)
                 self._graph.pop(next(iter(self._graph)))          # least recently used (dicts keep insertion order; a hit re-inserts)
             dev = self.layers[0][0].device
             static = {n: torch.empty(tuple(t.shape), dtype=t.dtype, device=dev) for n, t in host.items()}
@@ -406,6 +407,7 @@ class _PackedEncoder:
                 big = [k_ for k_ in self._graph if k_[0] == "large"]
                 key = ("large", B, Tp, lb)
                 if key not in self._graph and len(big) >= self.MAX_LARGE_GRAPHS:
+                    torch.cuda.current_stream(self.layers[0][0].device).synchronize()   # (its last replay may still run)
                     self._graph.pop(big[0])                       # each holds the activations of ~Tp tokens: keep few
                 out = self._replay(key, padded, to_dev, lb)
                 if out is not None:
